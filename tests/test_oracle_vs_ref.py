@@ -1,0 +1,87 @@
+"""The C restatement against the reference build itself (oracle/_ref/libdsc_ref.so),
+on fresh random inputs.  Skipped where _ref has not been built.  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import port, ref
+
+pytestmark = pytest.mark.skipif(not ref.available(), reason='oracle/_ref not built (needs /root/reference)')
+
+DTS = [np.float32, np.float64, np.complex64, np.complex128]
+
+
+def rnd(rng, shape, dt):
+    x = rng.standard_normal(shape)
+    if np.dtype(dt).kind == 'c':
+        x = x + 1j * rng.standard_normal(shape)
+    return x.astype(dt)
+
+
+def same(a, b, dt):
+    """Same flags, same operation order: expect identity; allow a few ulp in case the two
+    compilers contract differently."""
+    assert a.shape == b.shape and a.dtype == b.dtype
+    tol = 2e-6 if np.dtype(dt).itemsize in (4,) or np.dtype(dt) == np.complex64 else 4e-15
+    den = max(np.max(np.abs(b)), 1e-300)
+    assert np.max(np.abs(a - b)) / den <= tol
+
+
+def test_fft_all_axes_like_reference_test():
+    """Mirror of python/tests/test_ops.py:458-489 (every axis of an [8,8,8,8] tensor, crop /
+    copy / pad), for f64 as there and for f32 as well."""
+    R = ref.Ref.get()
+    rng = np.random.default_rng(5)
+    for dt, cdt in ((np.float64, np.complex128), (np.float32, np.complex64)):
+        n_ = 5
+        for axis in range(4):
+            shape = [8] * 4
+            shape[axis] = 2 ** n_
+            for change in (-1, 0, 1):
+                n = 2 ** (n_ + change)
+                x = rnd(rng, shape, dt)
+                same(port.rfft(x, n, axis), R.rfft(x, n, axis), dt)
+                X = R.rfft(x, n, axis)
+                same(port.irfft(X, -1, axis), R.irfft(X, -1, axis), dt)
+                xc = rnd(rng, shape, cdt)
+                same(port.fft(xc, n, axis), R.fft(xc, n, axis), cdt)
+                same(port.ifft(xc, n, axis), R.ifft(xc, n, axis), cdt)
+                same(port.fft(x, n, axis), R.fft(x, n, axis), cdt)
+
+
+def test_headline_size():
+    R = ref.Ref.get()
+    rng = np.random.default_rng(6)
+    x = rnd(rng, (3, 65536), np.float32)
+    X = R.rfft(x)
+    same(port.rfft(x), X, np.float32)
+    same(port.irfft(X), R.irfft(X), np.float32)
+
+
+def test_mul_reduce_cast():
+    R = ref.Ref.get()
+    rng = np.random.default_rng(7)
+    for da in DTS:
+        for db in DTS:
+            for sa, sb in (((4, 5), (4, 5)), ((4, 5), (5,)), ((4, 5), (1,)), ((1,), (4, 5)), ((3, 1, 5), (1, 4, 1))):
+                a, b = rnd(rng, sa, da), rnd(rng, sb, db)
+                same(port.mul(a, b), R.mul(a, b), np.result_type(da))
+            x = rnd(rng, (3, 4), da)
+            assert np.array_equal(port.cast(x, db), R.cast(x, db))
+    for dt in DTS:
+        for axis in range(-3, 3):
+            for keep in (True, False):
+                for op in range(4):
+                    x = rnd(rng, (7, 5, 3), dt)
+                    same(port.reduce(x, op, axis, keep), R.reduce(x, op, axis, keep), dt)
+
+
+def test_plan_table_layout():
+    """dsc_fft.h:33-55 / 109-135: table size and the stage layout."""
+    tw = port.plan_table(32768, np.float32, 0)
+    assert tw.size == 131070                      # 524,280 B
+    assert tw[0] == 1.0 and tw[1] == 0.0          # stage m=2, k=0
+    base = 2 * (32768 - 1)                        # stage m=65536 used by the real post-pass
+    k = np.arange(32768)
+    want = np.exp(-2j * np.pi * k / 65536)
+    got = tw[base::2] + 1j * tw[base + 1::2]
+    assert np.max(np.abs(got - want)) < 3e-7
