@@ -1,0 +1,13 @@
+"""dsc_amd — MI355X (gfx950) backend for the FFT hot path of dspcraft/dsc.
+
+Python mirror of the reference's `dsc` package for the operators on that path
+(python/dsc/__init__.py:7-57): init / clear, Tensor, from_numpy, mul, sum / mean / max / min,
+fft / ifft / rfft / irfft, plus filter_fft (fused README filterFFT).  Everything calls the
+C ABI in include/dsc_mi355x.h through ctypes; importing this package without the built
+library raises."""
+from .context import clear, init, last_fft_path, shutdown, synchronize, used_mem
+from .dtype import Dtype
+from .tensor import (Tensor, empty, fft, filter_fft, from_numpy, ifft, irfft, max, mean, min, mul, plan_fft, rfft, sum)
+
+__all__ = ['init', 'clear', 'shutdown', 'synchronize', 'used_mem', 'last_fft_path', 'Dtype', 'Tensor', 'empty',
+           'from_numpy', 'mul', 'sum', 'mean', 'max', 'min', 'plan_fft', 'fft', 'ifft', 'rfft', 'irfft', 'filter_fft']

@@ -1,0 +1,79 @@
+// arena.cpp — HBM arena bookkeeping (host side).
+//
+// Policy mirrors the reference's two allocators, restated for a device buffer whose bytes
+// the host cannot touch:
+//   main    best fit over an address-ordered free list, split on alloc, coalesce with both
+//           neighbours on free           (dsc/src/dsc_allocator.cpp:51-221)
+//   scratch bump pointer, reset as a whole (dsc/src/dsc_allocator.cpp:226-304)
+#include "dsc_internal.h"
+
+void dsc_main_arena::init(char *base, size_t size) {
+    base_ = base;
+    size_ = size;
+    clear();
+}
+
+void dsc_main_arena::clear() {
+    free_.clear();
+    live_.clear();
+    free_[0] = size_;
+    used_ = 0;
+}
+
+char *dsc_main_arena::alloc(size_t nb) {
+    DSC_ASSERT(nb > 0);
+    const size_t need = DSC_ALIGN_UP(nb, DSC_DEVICE_ALIGN);
+
+    auto best = free_.end();
+    for (auto it = free_.begin(); it != free_.end(); ++it) {
+        if (it->second >= need && (best == free_.end() || it->second < best->second)) best = it;
+    }
+    if (best == free_.end()) {
+        DSC_LOG_FATAL("error allocating %.2fKB in the main HBM arena (%.1f of %.1f MB in use)",
+                      (double) need / 1024., (double) used_ / 1048576., (double) size_ / 1048576.);
+    }
+    const size_t off = best->first;
+    const size_t left = best->second - need;
+    free_.erase(best);
+    if (left > 0) free_[off + need] = left;
+    live_[off] = need;
+    used_ += need;
+    return base_ + off;
+}
+
+void dsc_main_arena::free(char *p) {
+    if (p == nullptr) return;
+    const size_t off = (size_t) (p - base_);
+    auto it = live_.find(off);
+    if (it == live_.end()) return;             // double free / stale pointer: ignore
+    size_t size = it->second;
+    live_.erase(it);
+    used_ -= size;
+
+    size_t start = off;
+    auto next = free_.lower_bound(off);
+    if (next != free_.end() && next->first == off + size) {       // merge with the block after
+        size += next->second;
+        next = free_.erase(next);
+    }
+    if (next != free_.begin()) {                                   // merge with the block before
+        auto prev = std::prev(next);
+        if (prev->first + prev->second == off) {
+            start = prev->first;
+            size += prev->second;
+            free_.erase(prev);
+        }
+    }
+    free_[start] = size;
+}
+
+char *dsc_scratch_arena::alloc(size_t nb) {
+    const size_t need = DSC_ALIGN_UP(nb, DSC_DEVICE_ALIGN);
+    if (top_ + need > size_) {
+        DSC_LOG_FATAL("error allocating %.2fKB in the scratch HBM arena (%.1f of %.1f MB in use)",
+                      (double) need / 1024., (double) top_ / 1048576., (double) size_ / 1048576.);
+    }
+    char *p = base_ + top_;
+    top_ += need;
+    return p;
+}

@@ -1,0 +1,140 @@
+// dsc_internal.h — host-side internals of the MI355X backend (context, HBM arenas,
+// plan cache).  Not part of the C ABI (include/dsc_mi355x.h).
+#pragma once
+
+#include "dsc_mi355x.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+// Error convention of the reference (dsc/include/dsc.h:14-28): message on stderr, exit.
+#define DSC_LOG_FATAL(format, ...)                                        \
+    do {                                                                  \
+        fprintf(stderr, "%s: " format "\n", __func__, ##__VA_ARGS__);    \
+        exit(EXIT_FAILURE);                                               \
+    } while (0)
+
+#define DSC_LOG_INFO(format, ...) fprintf(stdout, "%s: " format "\n", __func__, ##__VA_ARGS__)
+
+#define DSC_ASSERT(x)                                                             \
+    do {                                                                          \
+        if (!(x)) {                                                               \
+            fprintf(stderr, "DSC_ASSERT: %s:%d %s\n", __FILE__, __LINE__, #x);    \
+            exit(EXIT_FAILURE);                                                   \
+        }                                                                         \
+    } while (0)
+
+#define HIP_CHECK(call)                                                                       \
+    do {                                                                                      \
+        hipError_t err_ = (call);                                                             \
+        if (err_ != hipSuccess) {                                                             \
+            fprintf(stderr, "HIP error %s:%d: %s -> %s\n", __FILE__, __LINE__, #call,        \
+                    hipGetErrorString(err_));                                                 \
+            exit(EXIT_FAILURE);                                                               \
+        }                                                                                     \
+    } while (0)
+
+#define DSC_ALIGN_UP(x, y) (((x) + (y) - 1) & ~((size_t) (y) - 1))
+#define DSC_DEVICE_ALIGN ((size_t) 256)
+#define DSC_MAX_FFT_PLANS 16                     // dsc/src/dsc.cpp:19-21
+
+static inline size_t dsc_dtype_size(dsc_dtype t) {   // dsc_dtype.h:58-63
+    static const size_t sz[4] = {4, 8, 8, 16};
+    DSC_ASSERT(t < 4);
+    return sz[t];
+}
+static inline bool dsc_is_complex(dsc_dtype t) { return t == DSC_C32 || t == DSC_C64; }
+static inline bool dsc_is_single(dsc_dtype t) { return t == DSC_F32 || t == DSC_C32; }
+
+// dsc/include/dsc.h:81 (dsc_tensor_dim): user axis -> slot in the 4-wide arrays
+static inline int dsc_axis_slot(const dsc_tensor *x, int axis) {
+    return axis < 0 ? DSC_MAX_DIMS + axis : DSC_MAX_DIMS - x->n_dim + axis;
+}
+
+// dsc/include/dsc.h:122-132
+static inline int dsc_pow2_n(int n) {
+    DSC_ASSERT(n > 0);
+    int p = n - 1;
+    p |= p >> 1; p |= p >> 2; p |= p >> 4; p |= p >> 8; p |= p >> 16;
+    return p + 1;
+}
+
+// ---------------------------------------------------------------------------------
+// HBM arenas.  The reference keeps allocator nodes inside the arena bytes
+// (dsc/src/dsc_allocator.cpp:34-49); a device arena cannot, so the bookkeeping is
+// host-side and the arena holds payload only.
+
+// Main arena: best-fit free list with coalescing of neighbours on free — the policy of
+// dsc_generic_allocator (dsc_allocator.cpp:51-221).
+class dsc_main_arena {
+public:
+    void init(char *base, size_t size);
+    char *alloc(size_t nb);              // fatal when no block fits (dsc_allocator.cpp:112-114)
+    void free(char *p);                  // unknown / already freed pointers are ignored (:152-181)
+    void clear();
+    size_t used() const { return used_; }
+    size_t capacity() const { return size_; }
+
+private:
+    char *base_ = nullptr;
+    size_t size_ = 0, used_ = 0;
+    std::map<size_t, size_t> free_;                 // offset -> size, address ordered
+    std::unordered_map<size_t, size_t> live_;       // offset -> size
+};
+
+// Scratch arena: bump pointer, reset as a whole (dsc_allocator.cpp:226-304).  Work on one
+// in-order stream makes reuse after reset safe without waiting.
+class dsc_scratch_arena {
+public:
+    void init(char *base, size_t size) { base_ = base; size_ = size; top_ = 0; }
+    char *alloc(size_t nb);
+    void reset() { top_ = 0; }
+    size_t capacity() const { return size_; }
+
+private:
+    char *base_ = nullptr;
+    size_t size_ = 0, top_ = 0;
+};
+
+// Our buffer record: `pub.refs` first so that &rec->pub is the ABI's dsc_tensor_buffer*.
+struct dsc_buffer_rec {
+    dsc_tensor_buffer pub;
+    char *dev;                // arena block (NULL for buffers living in scratch)
+    size_t nbytes;
+};
+
+// A plan = device twiddle tables for one (n, fft_type, precision): dsc_fft.h:18-27.
+struct dsc_fft_plan {
+    int n;                    // complex length of the transform (pow2)
+    int last_used;
+    dsc_dtype dtype;          // DSC_F32 or DSC_F64 (twiddle precision)
+    dsc_fft_type fft_type;
+    void *tw_full;            // W_n^k, k in [0, n): interleaved (cos, sin), device
+    void *tw_real;            // REAL plans: W_{2n}^k, k in [0, n/2]: post/pre-pass factors
+    void *tw_aux;             // kernel-specific tables (register-resident kernels)
+    char *block;              // arena block holding the above
+};
+
+struct dsc_ctx {
+    int device;
+    hipStream_t stream;
+    hipEvent_t ev_start, ev_stop;
+    char *main_buf, *scratch_buf;
+    dsc_main_arena main;
+    dsc_scratch_arena scratch;
+    dsc_fft_plan *fft_plans[DSC_MAX_FFT_PLANS];
+    std::unordered_set<dsc_tensor *> live_tensors;     // tolerate double frees (tensor.py __del__)
+    std::vector<dsc_tensor *> tensor_pool;             // recycled headers
+    const char *last_fft_path;
+    int n_cu;
+};
+
+// internal helpers shared by the C-ABI translation units
+dsc_tensor *dsc_new_tensor_in(dsc_ctx *ctx, int n_dim, const int *shape, dsc_dtype dtype,
+                              dsc_tensor_buffer *buffer, bool in_scratch);

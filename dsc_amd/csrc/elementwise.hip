@@ -1,0 +1,133 @@
+// elementwise.hip — dtype cast and broadcast binary operators (HBM-bound streaming kernels).
+//
+// Reference: dsc_cast (dsc/src/dsc.cpp:536-597, cast_op dsc/include/dsc_ops.h:12-44) and
+// binary_op (dsc/src/dsc.cpp:1186-1245) with mul_op & co. (dsc_ops.h:46-90).  The reference
+// walks two dsc_broadcast_iterators per element (dsc_iter.h:67-95); here the output's flat
+// index is decomposed once per element and each operand offset is a dot product with its
+// broadcast strides (0 on broadcast dims), so equal-shape, row-broadcast and scalar operands
+// all stream at the same rate.
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+namespace {
+
+template<typename T> struct alignas(2 * sizeof(T)) cx { T x, y; };
+
+template<typename T> struct elem;   // dtype code -> storage type
+template<> struct elem<float>  { static constexpr bool cplx = false; using real = float; };
+template<> struct elem<double> { static constexpr bool cplx = false; using real = double; };
+template<> struct elem<cx<float>>  { static constexpr bool cplx = true; using real = float; };
+template<> struct elem<cx<double>> { static constexpr bool cplx = true; using real = double; };
+
+// cast_op (dsc_ops.h:12-44): complex -> real keeps .real; real -> complex sets imag = 0
+template<typename Tin, typename Tout>
+__device__ __forceinline__ Tout cast_one(Tin v) {
+    using Rout = typename elem<Tout>::real;
+    if constexpr (elem<Tout>::cplx) {
+        if constexpr (elem<Tin>::cplx) return Tout{(Rout) v.x, (Rout) v.y};
+        else                           return Tout{(Rout) v, (Rout) 0};
+    } else {
+        if constexpr (elem<Tin>::cplx) return (Rout) v.x;
+        else                           return (Rout) v;
+    }
+}
+
+template<typename Tin, typename Tout>
+__global__ void cast_kernel(const Tin *in, Tout *out, long long ne) {
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < ne; i += (long long) gridDim.x * blockDim.x)
+        out[i] = cast_one<Tin, Tout>(in[i]);
+}
+
+template<typename Tin>
+void cast_from(const void *in, void *out, int out_dtype, long long ne, dim3 grid, hipStream_t s) {
+    const Tin *x = (const Tin *) in;
+    switch (out_dtype) {
+        case 0: hipLaunchKernelGGL((cast_kernel<Tin, float>), grid, dim3(256), 0, s, x, (float *) out, ne); break;
+        case 1: hipLaunchKernelGGL((cast_kernel<Tin, double>), grid, dim3(256), 0, s, x, (double *) out, ne); break;
+        case 2: hipLaunchKernelGGL((cast_kernel<Tin, cx<float>>), grid, dim3(256), 0, s, x, (cx<float> *) out, ne); break;
+        default: hipLaunchKernelGGL((cast_kernel<Tin, cx<double>>), grid, dim3(256), 0, s, x, (cx<double> *) out, ne); break;
+    }
+}
+
+// add_op / sub_op / mul_op / div_op: dsc_ops.h:46-90
+template<typename T, int OP>
+__device__ __forceinline__ T apply(T a, T b) {
+    if constexpr (elem<T>::cplx) {
+        if constexpr (OP == 0) return T{a.x + b.x, a.y + b.y};
+        else if constexpr (OP == 1) return T{a.x - b.x, a.y - b.y};
+        else if constexpr (OP == 2) return T{(a.x * b.x) - (a.y * b.y), (a.x * b.y) + (a.y * b.x)};
+        else {
+            const auto den = (b.x * b.x) + (b.y * b.y);
+            return T{((a.x * b.x) + (a.y * b.y)) / den, ((a.y * b.x) - (a.x * b.y)) / den};
+        }
+    } else {
+        if constexpr (OP == 0) return a + b;
+        else if constexpr (OP == 1) return a - b;
+        else if constexpr (OP == 2) return a * b;
+        else return a / b;
+    }
+}
+
+template<typename T, int OP>
+__global__ void binary_kernel(const T *a, const T *b, T *out, const dsc_bcast_args g) {
+    const long long s3 = g.out_shape[3];
+    const long long s23 = s3 * g.out_shape[2];
+    const long long s123 = s23 * g.out_shape[1];
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < g.ne; i += (long long) gridDim.x * blockDim.x) {
+        long long ia, ib;
+        if (g.a_scalar)      { ia = 0; ib = i; }
+        else if (g.b_scalar) { ia = i; ib = 0; }
+        else {
+            const long long i0 = i / s123, r0 = i - i0 * s123;
+            const long long i1 = r0 / s23, r1 = r0 - i1 * s23;
+            const long long i2 = r1 / s3, i3 = r1 - i2 * s3;
+            ia = i0 * g.a_stride[0] + i1 * g.a_stride[1] + i2 * g.a_stride[2] + i3 * g.a_stride[3];
+            ib = i0 * g.b_stride[0] + i1 * g.b_stride[1] + i2 * g.b_stride[2] + i3 * g.b_stride[3];
+        }
+        out[i] = apply<T, OP>(a[ia], b[ib]);
+    }
+}
+
+template<typename T>
+void binary_typed(const void *a, const void *b, void *out, int op, const dsc_bcast_args &g, dim3 grid, hipStream_t s) {
+    const T *pa = (const T *) a, *pb = (const T *) b;
+    T *po = (T *) out;
+    switch (op) {
+        case 0: hipLaunchKernelGGL((binary_kernel<T, 0>), grid, dim3(256), 0, s, pa, pb, po, g); break;
+        case 1: hipLaunchKernelGGL((binary_kernel<T, 1>), grid, dim3(256), 0, s, pa, pb, po, g); break;
+        case 2: hipLaunchKernelGGL((binary_kernel<T, 2>), grid, dim3(256), 0, s, pa, pb, po, g); break;
+        default: hipLaunchKernelGGL((binary_kernel<T, 3>), grid, dim3(256), 0, s, pa, pb, po, g); break;
+    }
+}
+
+inline dim3 stream_grid(long long ne) {
+    long long blocks = (ne + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;        // 8 blocks per CU, grid-stride beyond that
+    if (blocks < 1) blocks = 1;
+    return dim3((unsigned) blocks);
+}
+
+}  // namespace
+
+void dsc_launch_cast(const void *in, int in_dtype, void *out, int out_dtype, long long ne, hipStream_t stream) {
+    if (ne <= 0) return;
+    const dim3 grid = stream_grid(ne);
+    switch (in_dtype) {
+        case 0: cast_from<float>(in, out, out_dtype, ne, grid, stream); break;
+        case 1: cast_from<double>(in, out, out_dtype, ne, grid, stream); break;
+        case 2: cast_from<cx<float>>(in, out, out_dtype, ne, grid, stream); break;
+        default: cast_from<cx<double>>(in, out, out_dtype, ne, grid, stream); break;
+    }
+}
+
+void dsc_launch_binary(const void *a, const void *b, void *out, int dtype, int op, const dsc_bcast_args &g, hipStream_t stream) {
+    if (g.ne <= 0) return;
+    const dim3 grid = stream_grid(g.ne);
+    switch (dtype) {
+        case 0: binary_typed<float>(a, b, out, op, g, grid, stream); break;
+        case 1: binary_typed<double>(a, b, out, op, g, grid, stream); break;
+        case 2: binary_typed<cx<float>>(a, b, out, op, g, grid, stream); break;
+        default: binary_typed<cx<double>>(a, b, out, op, g, grid, stream); break;
+    }
+}

@@ -1,0 +1,358 @@
+// fft_driver.cpp — dsc_plan_fft / dsc_fft / dsc_ifft / dsc_rfft / dsc_irfft / dsc_filter_fft.
+//
+// Host-side mirror of the reference drivers: plan cache dsc/src/dsc.cpp:182-267, shape and
+// dtype rules :2009-2071 (fft) and :2173-2244 (rfft), public entry points :2073-2100,
+// :2246-2260.  Where the reference loops over lines on the host (exec_fft :1958-2007,
+// exec_rfft :2102-2171), this file picks a kernel path for the whole batch:
+//
+//   r2c_64k_regs / c2r_64k_regs   f32, 65536-point real transform of contiguous rows:
+//                                  register-resident, one HBM round trip (fft_r2c_64k.hip)
+//   generic_lds                    complex length <= dsc_fft_lds_max_len: one pass (fft_generic.hip)
+//   generic_4step                  longer: pack -> columns(+twiddle) -> rows -> post/unpack,
+//                                  chunked over lines to fit the scratch arena
+#include "dsc_internal.h"
+#include "kernels.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+// exp(-2 pi i k / n) with exact values on the axes: quarter-turn reduction, long double.
+static void unit_root(long long k, long long n, long double *c, long double *s) {
+    k %= n;
+    const long long q = (4 * k) / n;
+    const long long r = 4 * k - q * n;
+    const long double a = 1.57079632679489661923132169163975144L * (long double) r / (long double) n;
+    const long double cr = r == 0 ? 1.0L : cosl(a), sr = r == 0 ? 0.0L : sinl(a);
+    switch (q) {
+        case 0:  *c = cr;  *s = -sr; break;
+        case 1:  *c = -sr; *s = -cr; break;
+        case 2:  *c = -cr; *s = sr;  break;
+        default: *c = sr;  *s = cr;  break;
+    }
+}
+
+template<typename T>
+static void fill_roots(T *dst, long long count, long long n) {
+    for (long long k = 0; k < count; ++k) {
+        long double c, s;
+        unit_root(k, n, &c, &s);
+        dst[2 * k] = (T) c;
+        dst[2 * k + 1] = (T) s;
+    }
+}
+
+// dsc.cpp:182-216
+static dsc_fft_plan *find_plan(dsc_ctx *ctx, int n, dsc_fft_type fft_type, dsc_dtype twd_dtype) {
+    dsc_fft_plan *plan = nullptr;
+    for (int i = 0; i < DSC_MAX_FFT_PLANS; ++i) {
+        dsc_fft_plan *cached = ctx->fft_plans[i];
+        if (cached == nullptr) continue;
+        if (cached->n == n && cached->fft_type == fft_type && cached->dtype == twd_dtype) {
+            plan = cached;
+            plan->last_used = 0;
+        } else {
+            cached->last_used++;
+        }
+    }
+    return plan;
+}
+
+// dsc.cpp:218-267.  The reference's table is the concatenation of every radix-2 stage's
+// twiddles in the transform precision (dsc_fft.h:33-55); ours is one table of the n-th
+// roots (every stage indexes it with a stride) plus, for REAL plans, the 2n-th roots of the
+// packed-real pass, all rounded once from long double.
+extern "C" dsc_fft_plan *dsc_plan_fft(dsc_ctx *ctx, int n, dsc_fft_type fft_type, dsc_dtype dtype) {
+    DSC_ASSERT(dtype < 4);
+    DSC_ASSERT(fft_type == DSC_FFT_REAL || fft_type == DSC_FFT_COMPLEX);
+    const int fft_n = dsc_pow2_n(n);
+    const dsc_dtype twd = dsc_is_single(dtype) ? DSC_F32 : DSC_F64;
+
+    dsc_fft_plan *plan = find_plan(ctx, fft_n, fft_type, twd);
+    if (plan != nullptr) return plan;
+
+    int slot = -1;
+    for (int i = 0; i < DSC_MAX_FFT_PLANS; ++i) {
+        if (ctx->fft_plans[i] == nullptr) { slot = i; break; }
+    }
+    if (slot < 0) {                                     // evict the least recently used
+        int oldest = -1;
+        for (int i = 0; i < DSC_MAX_FFT_PLANS; ++i) {
+            if (ctx->fft_plans[i]->last_used > oldest) { oldest = ctx->fft_plans[i]->last_used; slot = i; }
+        }
+        ctx->main.free(ctx->fft_plans[slot]->block);
+        delete ctx->fft_plans[slot];
+        ctx->fft_plans[slot] = nullptr;
+    }
+
+    const size_t real_sz = twd == DSC_F32 ? 4 : 8;
+    const bool regs64k = fft_type == DSC_FFT_REAL && twd == DSC_F32 && fft_n == 32768;
+    const size_t full_bytes = DSC_ALIGN_UP((size_t) fft_n * 2 * real_sz, DSC_DEVICE_ALIGN);
+    const size_t real_bytes = fft_type == DSC_FFT_REAL ? DSC_ALIGN_UP(((size_t) fft_n + 1) * 2 * real_sz, DSC_DEVICE_ALIGN) : 0;
+    const size_t aux_bytes = regs64k ? DSC_ALIGN_UP(dsc_r2c64k_table_bytes(), DSC_DEVICE_ALIGN) : 0;
+    const size_t total = full_bytes + real_bytes + aux_bytes;
+
+    std::vector<char> host(total, 0);
+    if (twd == DSC_F32) {
+        fill_roots((float *) host.data(), fft_n, fft_n);
+        if (real_bytes) fill_roots((float *) (host.data() + full_bytes), (long long) fft_n + 1, 2LL * fft_n);
+    } else {
+        fill_roots((double *) host.data(), fft_n, fft_n);
+        if (real_bytes) fill_roots((double *) (host.data() + full_bytes), (long long) fft_n + 1, 2LL * fft_n);
+    }
+    if (aux_bytes) dsc_r2c64k_build_tables(host.data() + full_bytes + real_bytes);
+
+    plan = new dsc_fft_plan();
+    plan->n = fft_n;
+    plan->last_used = 0;
+    plan->dtype = twd;
+    plan->fft_type = fft_type;
+    plan->block = ctx->main.alloc(total);
+    plan->tw_full = plan->block;
+    plan->tw_real = real_bytes ? plan->block + full_bytes : nullptr;
+    plan->tw_aux = aux_bytes ? plan->block + full_bytes + real_bytes : nullptr;
+    HIP_CHECK(hipMemcpyAsync(plan->block, host.data(), total, hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));       // `host` dies at return
+    ctx->fft_plans[slot] = plan;
+    return plan;
+}
+
+// ---------------------------------------------------------------------------------------------
+
+struct fft_job {
+    const dsc_tensor *x;
+    dsc_tensor *out;
+    int slot;            // transformed axis (0..3)
+    int in_len;          // valid samples to read along the axis (input element units)
+    int L;               // complex transform length
+    dsc_fft_mode mode;
+    bool inverse;
+    double scale;
+};
+
+static void lines_of(const dsc_tensor *t, int slot, long long *n_lines, long long *inner, dsc_line_layout *l) {
+    long long in = 1;
+    for (int i = slot + 1; i < DSC_MAX_DIMS; ++i) in *= t->shape[i];
+    long long outer = 1;
+    for (int i = 0; i < slot; ++i) outer *= t->shape[i];
+    *inner = in;
+    *n_lines = outer * in;
+    l->inner_stride = 1;
+    l->elem_stride = in;
+    l->outer_stride = (long long) t->shape[slot] * in;
+}
+
+static void run_four_step(dsc_ctx *ctx, const fft_job &j, bool sp, const dsc_fft_plan *real_plan) {
+    const int lds_max = dsc_fft_lds_max_len(sp);
+    const int L = j.L, L2 = lds_max, L1 = L / L2;
+    DSC_ASSERT(L1 >= 2 && L1 <= lds_max);
+    const dsc_dtype cdt = sp ? DSC_C32 : DSC_C64;
+    const dsc_fft_plan *p1 = dsc_plan_fft(ctx, L1, DSC_FFT_COMPLEX, cdt);
+    const dsc_fft_plan *p2 = dsc_plan_fft(ctx, L2, DSC_FFT_COMPLEX, cdt);
+
+    long long n_lines, inner_in, inner_out;
+    dsc_line_layout lin, lout;
+    lines_of(j.x, j.slot, &n_lines, &inner_in, &lin);
+    lines_of(j.out, j.slot, &n_lines, &inner_out, &lout);
+
+    const size_t line_bytes = (size_t) L * dsc_dtype_size(cdt);
+    ctx->scratch.reset();
+    long long chunk = (long long) ((ctx->scratch.capacity() - 2 * DSC_DEVICE_ALIGN) / (2 * line_bytes));
+    if (chunk < 1)
+        DSC_LOG_FATAL("scratch arena too small: a %d-point transform needs %.1f MB of scratch", L, 2.0 * line_bytes / 1048576.);
+    if (chunk > n_lines) chunk = n_lines;
+    char *A = ctx->scratch.alloc((size_t) chunk * line_bytes);
+    char *B = ctx->scratch.alloc((size_t) chunk * line_bytes);
+
+    for (long long q = 0; q < n_lines; q += chunk) {
+        const long long nl = n_lines - q < chunk ? n_lines - q : chunk;
+        if (j.mode == DSC_MODE_C2R_PACKED)
+            dsc_launch_fft_c2r_prepass(j.x->data, A, q, nl, inner_in, lin, L, j.in_len, real_plan->tw_real, sp, ctx->stream);
+        else
+            dsc_launch_fft_pack(j.x->data, A, q, nl, inner_in, lin, L, j.in_len, j.mode, sp, ctx->stream);
+
+        dsc_fft_lines_args a;
+        // columns: L2 lines of length L1 per transform, times W_L^{j2 k1}
+        a.in = A; a.out = B;
+        a.n_lines = nl * L2; a.inner = L2;
+        a.lin = a.lout = dsc_line_layout{L, 1, L2};
+        a.L = L1; a.in_len = L1; a.inverse = j.inverse; a.scale = 1.0;
+        a.tw = p1->tw_full; a.tw_real = nullptr; a.tw4_len = L;
+        dsc_launch_fft_lines(a, DSC_MODE_C2C, sp, ctx->stream);
+        // rows: L1 lines of length L2, output k1 + L1 k2
+        a.in = B; a.out = A;
+        a.n_lines = nl * L1; a.inner = L1;
+        a.lin = dsc_line_layout{L, L2, 1};
+        a.lout = dsc_line_layout{L, 1, L1};
+        a.L = L2; a.in_len = L2; a.tw = p2->tw_full; a.tw4_len = 0;
+        dsc_launch_fft_lines(a, DSC_MODE_C2C, sp, ctx->stream);
+
+        if (j.mode == DSC_MODE_R2C_PACKED)
+            dsc_launch_fft_r2c_postpass(A, j.out->data, q, nl, inner_out, lout, L, real_plan->tw_real, sp, ctx->stream);
+        else
+            dsc_launch_fft_unpack(A, j.out->data, q, nl, inner_out, lout, L, j.scale, j.mode, sp, ctx->stream);
+    }
+    ctx->last_fft_path = "generic_4step";
+}
+
+static void run_job(dsc_ctx *ctx, const fft_job &j) {
+    const bool sp = dsc_is_single(j.out->dtype);
+    const bool packed = j.mode == DSC_MODE_R2C_PACKED || j.mode == DSC_MODE_C2R_PACKED;
+    const dsc_fft_plan *plan = dsc_plan_fft(ctx, j.L, packed ? DSC_FFT_REAL : DSC_FFT_COMPLEX, j.out->dtype);
+
+    long long n_lines, inner;
+    dsc_line_layout lin, lout;
+    lines_of(j.x, j.slot, &n_lines, &inner, &lin);
+    lines_of(j.out, j.slot, &n_lines, &inner, &lout);
+
+    // register-resident 65536-point real transforms: contiguous full rows only
+    if (sp && packed && j.L == 32768 && inner == 1 && plan->tw_aux != nullptr) {
+        if (j.mode == DSC_MODE_R2C_PACKED && j.in_len == 65536 && j.x->shape[j.slot] == 65536) {
+            dsc_launch_rfft64k((const float *) j.x->data, j.out->data, (int) n_lines, plan->tw_aux, ctx->n_cu, ctx->stream);
+            ctx->last_fft_path = "r2c_64k_regs";
+            return;
+        }
+        if (j.mode == DSC_MODE_C2R_PACKED && j.in_len == 32769 && j.x->shape[j.slot] == 32769) {
+            dsc_launch_irfft64k(j.x->data, (float *) j.out->data, (int) n_lines, plan->tw_aux, ctx->n_cu, ctx->stream);
+            ctx->last_fft_path = "c2r_64k_regs";
+            return;
+        }
+    }
+
+    if (j.L <= dsc_fft_lds_max_len(sp)) {
+        dsc_fft_lines_args a;
+        a.in = j.x->data; a.out = j.out->data;
+        a.n_lines = n_lines; a.inner = inner;
+        a.lin = lin; a.lout = lout;
+        a.L = j.L; a.in_len = j.in_len; a.inverse = j.inverse; a.scale = j.scale;
+        a.tw = plan->tw_full; a.tw_real = plan->tw_real; a.tw4_len = 0;
+        dsc_launch_fft_lines(a, j.mode, sp, ctx->stream);
+        ctx->last_fft_path = "generic_lds";
+        return;
+    }
+    run_four_step(ctx, j, sp, plan);
+}
+
+static dsc_tensor *make_out(dsc_ctx *ctx, const dsc_tensor *x, dsc_tensor *out, const int *out_shape, dsc_dtype out_dtype) {
+    if (out == nullptr)
+        return dsc_new_tensor(ctx, x->n_dim, &out_shape[DSC_MAX_DIMS - x->n_dim], out_dtype, nullptr);
+    DSC_ASSERT(out->dtype == out_dtype);
+    DSC_ASSERT(out->n_dim == x->n_dim);
+    DSC_ASSERT(memcmp(out_shape, out->shape, DSC_MAX_DIMS * sizeof(int)) == 0);
+    return out;
+}
+
+// dsc.cpp:2009-2071
+static dsc_tensor *internal_fft(dsc_ctx *ctx, const dsc_tensor *x, dsc_tensor *out, int n, int axis, bool forward) {
+    DSC_ASSERT(x != nullptr);
+    const int slot = dsc_axis_slot(x, axis);
+    DSC_ASSERT(slot >= 0 && slot < DSC_MAX_DIMS);
+    const int x_n = x->shape[slot];
+    n = n > 0 ? dsc_pow2_n(n) : dsc_pow2_n(x_n);
+
+    int out_shape[DSC_MAX_DIMS];
+    for (int i = 0; i < DSC_MAX_DIMS; ++i) out_shape[i] = i != slot ? x->shape[i] : n;
+    dsc_dtype out_dtype = x->dtype;
+    if (x->dtype == DSC_F32) out_dtype = DSC_C32;
+    else if (x->dtype == DSC_F64) out_dtype = DSC_C64;
+    out = make_out(ctx, x, out, out_shape, out_dtype);
+
+    fft_job j;
+    j.x = x; j.out = out; j.slot = slot;
+    j.in_len = x_n < n ? x_n : n;
+    j.L = n;
+    j.mode = dsc_is_complex(x->dtype) ? DSC_MODE_C2C : DSC_MODE_R2C_CAST;
+    j.inverse = !forward;
+    j.scale = forward ? 1.0 : 1.0 / (double) n;          // dsc_fft.h:168-175
+    run_job(ctx, j);
+    return out;
+}
+
+// dsc.cpp:2173-2244
+static dsc_tensor *internal_rfft(dsc_ctx *ctx, const dsc_tensor *x, dsc_tensor *out, int n, int axis, bool forward) {
+    DSC_ASSERT(x != nullptr);
+    const int slot = dsc_axis_slot(x, axis);
+    DSC_ASSERT(slot >= 0 && slot < DSC_MAX_DIMS);
+    const int x_n = x->shape[slot];
+
+    int out_n, order;
+    dsc_dtype out_dtype;
+    if (forward) {
+        order = (n > 0 ? dsc_pow2_n(n) : dsc_pow2_n(x_n)) >> 1;
+        out_n = order + 1;
+        if (x->dtype == DSC_F32) out_dtype = DSC_C32;
+        else if (x->dtype == DSC_F64) out_dtype = DSC_C64;
+        else DSC_LOG_FATAL("RFFT input must be real");
+    } else {
+        DSC_ASSERT((n > 0 ? n : x_n) > 1);
+        order = n > 0 ? dsc_pow2_n(n - 1) : dsc_pow2_n(x_n - 1);
+        out_n = order << 1;
+        if (x->dtype == DSC_C32) out_dtype = DSC_F32;
+        else if (x->dtype == DSC_C64) out_dtype = DSC_F64;
+        else DSC_LOG_FATAL("IRFFT input must be complex");
+    }
+    DSC_ASSERT(order >= 1);            // the reference asserts n > 0 in dsc_fft_storage (dsc_fft.h:112)
+
+    int out_shape[DSC_MAX_DIMS];
+    for (int i = 0; i < DSC_MAX_DIMS; ++i) out_shape[i] = i != slot ? x->shape[i] : out_n;
+    out = make_out(ctx, x, out, out_shape, out_dtype);
+
+    fft_job j;
+    j.x = x; j.out = out; j.slot = slot;
+    j.L = order;
+    j.inverse = !forward;
+    if (forward) {
+        j.mode = DSC_MODE_R2C_PACKED;
+        j.in_len = x_n < 2 * order ? x_n : 2 * order;         // dsc.cpp:2121, 2125-2133
+        j.scale = 1.0;
+    } else {
+        j.mode = DSC_MODE_C2R_PACKED;
+        j.in_len = x_n < order + 1 ? x_n : order + 1;         // dsc.cpp:2145, 2149-2157
+        j.scale = 2.0 / (double) (order << 1);                 // dsc_fft.h:232
+    }
+    run_job(ctx, j);
+    return out;
+}
+
+extern "C" dsc_tensor *dsc_fft(dsc_ctx *ctx, const dsc_tensor *x, dsc_tensor *out, int n, int axis) {
+    return internal_fft(ctx, x, out, n, axis, true);
+}
+extern "C" dsc_tensor *dsc_ifft(dsc_ctx *ctx, const dsc_tensor *x, dsc_tensor *out, int n, int axis) {
+    return internal_fft(ctx, x, out, n, axis, false);
+}
+extern "C" dsc_tensor *dsc_rfft(dsc_ctx *ctx, const dsc_tensor *x, dsc_tensor *out, int n, int axis) {
+    return internal_rfft(ctx, x, out, n, axis, true);
+}
+extern "C" dsc_tensor *dsc_irfft(dsc_ctx *ctx, const dsc_tensor *x, dsc_tensor *out, int n, int axis) {
+    return internal_rfft(ctx, x, out, n, axis, false);
+}
+
+// README.md:113-135 as one call.  Fused kernel for the 65536-point f32 case, otherwise the
+// three-operator composition the reference's users write by hand.
+extern "C" dsc_tensor *dsc_filter_fft(dsc_ctx *ctx, const dsc_tensor *s, const dsc_tensor *H, dsc_tensor *out) {
+    DSC_ASSERT(s != nullptr && H != nullptr);
+    DSC_ASSERT(dsc_is_complex(H->dtype));
+    const int bins = H->shape[DSC_MAX_DIMS - 1];
+    DSC_ASSERT(H->ne == bins && bins >= 2);
+    const int n = 2 * (bins - 1);
+    DSC_ASSERT((n & (n - 1)) == 0);
+
+    const int ls = s->shape[DSC_MAX_DIMS - 1];
+    if (s->dtype == DSC_F32 && H->dtype == DSC_C32 && n == 65536 && ls == 65536) {
+        int out_shape[DSC_MAX_DIMS];
+        memcpy(out_shape, s->shape, sizeof(out_shape));
+        out_shape[DSC_MAX_DIMS - 1] = n;
+        out = make_out(ctx, s, out, out_shape, DSC_F32);
+        const dsc_fft_plan *plan = dsc_plan_fft(ctx, 32768, DSC_FFT_REAL, DSC_C32);
+        dsc_launch_filter64k((const float *) s->data, H->data, (float *) out->data, s->ne / ls, plan->tw_aux, ctx->n_cu, ctx->stream);
+        ctx->last_fft_path = "filter_64k_regs";
+        return out;
+    }
+    dsc_tensor *S = dsc_rfft(ctx, s, nullptr, n, -1);
+    dsc_tensor *P = dsc_mul(ctx, S, const_cast<dsc_tensor *>(H), nullptr);
+    out = dsc_irfft(ctx, P, out, -1, -1);
+    dsc_tensor_free(ctx, S);
+    dsc_tensor_free(ctx, P);
+    ctx->last_fft_path = "filter_composed";
+    return out;
+}

@@ -1,0 +1,91 @@
+// kernels.h — host-callable launchers of the HIP kernels (gfx950).  Everything is enqueued
+// on the given stream; nothing here synchronises or allocates.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstddef>
+
+// A batch of 1-D lines inside a tensor.  Line q (0 <= q < n_lines) starts at element
+//   (q / inner) * outer_stride + (q % inner) * inner_stride
+// and advances by elem_stride per sample.  Strides are in elements of the array's own
+// element type (real or complex).  For a contiguous DSC tensor transformed along `axis`:
+// inner = prod(shape[axis+1:]), inner_stride = 1, elem_stride = inner,
+// outer_stride = shape[axis] * inner  — the lines dsc_axis_iterator walks
+// (reference: dsc/include/dsc_iter.h:11-65).
+struct dsc_line_layout {
+    long long outer_stride;
+    long long inner_stride;
+    long long elem_stride;
+};
+
+enum dsc_fft_mode {
+    DSC_MODE_C2C = 0,        // complex in  -> complex out          (dsc_fft / dsc_ifft)
+    DSC_MODE_R2C_CAST = 1,   // real in, cast to complex -> complex (dsc_fft on f32/f64, dsc.cpp:1984-1988)
+    DSC_MODE_R2C_PACKED = 2, // 2L reals -> L+1 bins                (dsc_rfft,  dsc_fft.h:178-225)
+    DSC_MODE_C2R_PACKED = 3, // L+1 bins -> 2L reals                (dsc_irfft, dsc_fft.h:194-236)
+};
+
+struct dsc_fft_lines_args {
+    const void *in;
+    void *out;
+    long long n_lines;
+    long long inner;
+    dsc_line_layout lin, lout;
+    int L;                 // complex transform length (power of two, <= dsc_fft_lds_max_len)
+    int in_len;            // valid input samples along the axis (reals for R2C_PACKED, bins for C2R); the rest reads as zero
+    int inverse;           // conjugate twiddles
+    double scale;          // multiplied into every output
+    const void *tw;        // W_L^k, k in [0, L)       interleaved (cos, sin), precision of the transform
+    const void *tw_real;   // W_{2L}^k, k in [0, L]    (packed modes only)
+    long long tw4_len;     // four-step: also multiply output k of line q by W_{tw4_len}^{(q % inner) * k}; 0 = off
+};
+
+// Largest complex length the LDS line kernel handles for the given precision.
+int dsc_fft_lds_max_len(bool single_precision);
+
+// One pass over HBM: gather -> Stockham radix-4/2 in LDS -> (real post-pass) -> scatter.
+void dsc_launch_fft_lines(const dsc_fft_lines_args &a, dsc_fft_mode mode, bool single_precision, hipStream_t stream);
+
+// Helpers of the multi-pass (four-step) path: contiguous [n_lines][L] complex work buffers holding
+// tensor lines q_first .. q_first + n_lines - 1.
+//   pack     tensor lines -> work (zero-pad / crop / cast / pair-up reals), per `mode`
+//   prepass  C2R: bins in work-like layout -> Z = h1 + conj(w) h2           (dsc_fft.h:194-228)
+//   postpass R2C: Z (work) -> L+1 bins scattered to the tensor               (dsc_fft.h:199-225)
+//   unpack   work -> tensor lines (complex, or 2L reals for C2R) times scale
+void dsc_launch_fft_pack(const void *in, void *work, long long q_first, long long n_lines, long long inner, dsc_line_layout lin,
+                         int L, int in_len, dsc_fft_mode mode, bool single_precision, hipStream_t stream);
+void dsc_launch_fft_c2r_prepass(const void *in, void *work, long long q_first, long long n_lines, long long inner, dsc_line_layout lin,
+                                int L, int in_len, const void *tw_real, bool single_precision, hipStream_t stream);
+void dsc_launch_fft_r2c_postpass(const void *work, void *out, long long q_first, long long n_lines, long long inner, dsc_line_layout lout,
+                                 int L, const void *tw_real, bool single_precision, hipStream_t stream);
+void dsc_launch_fft_unpack(const void *work, void *out, long long q_first, long long n_lines, long long inner, dsc_line_layout lout,
+                           int L, double scale, dsc_fft_mode mode, bool single_precision, hipStream_t stream);
+
+// ---- register-resident 65536-point real transforms (f32), one HBM round trip ------------
+// x: [batch][65536] f32 contiguous rows; X: [batch][32769] c32 contiguous rows.
+// aux: tables built by dsc_r2c64k_build_tables (device pointer).
+size_t dsc_r2c64k_table_bytes();
+void   dsc_r2c64k_build_tables(void *host_dst);          // fills a host staging buffer of table_bytes
+void   dsc_launch_rfft64k(const float *x, void *X, int batch, const void *aux, int n_cu, hipStream_t stream);
+void   dsc_launch_irfft64k(const void *X, float *x, int batch, const void *aux, int n_cu, hipStream_t stream);
+// y = irfft(rfft(s) * H) fused; H: [32769] c32
+void   dsc_launch_filter64k(const float *s, const void *H, float *y, int batch, const void *aux, int n_cu, hipStream_t stream);
+
+// ---- element-wise ------------------------------------------------------------------------
+// dtype codes are dsc_dtype values (0 f32, 1 f64, 2 c32, 3 c64)
+void dsc_launch_cast(const void *in, int in_dtype, void *out, int out_dtype, long long ne, hipStream_t stream);
+
+struct dsc_bcast_args {
+    int out_shape[4];
+    int a_stride[4];       // element strides, 0 on broadcast dims (dsc_iter.h:67-95)
+    int b_stride[4];
+    long long ne;
+    int a_scalar, b_scalar;   // reference's scalar fast paths (dsc.cpp:1194-1212)
+};
+// op: 0 add, 1 sub, 2 mul, 3 div   (only mul is exported through the C ABI this round)
+void dsc_launch_binary(const void *a, const void *b, void *out, int dtype, int op, const dsc_bcast_args &g, hipStream_t stream);
+
+// ---- reductions along one axis -----------------------------------------------------------
+// x viewed as [outer][axis_n][inner] contiguous; out as [outer][inner].
+// op: 0 sum, 1 mean, 2 max, 3 min
+void dsc_launch_reduce(const void *x, void *out, int dtype, int op, long long outer, int axis_n, long long inner, hipStream_t stream);

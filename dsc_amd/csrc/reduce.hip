@@ -1,0 +1,145 @@
+// reduce.hip — sum / mean / max / min along one axis.
+//
+// Reference: dsc/src/dsc.cpp:1771-1953 (one sequential accumulation in T per output element,
+// source index from dsc_axis_iterator) with add_op / max_op / min_op (dsc_ops.h:46-55,
+// 318-339).  The tensor is viewed as [outer][axis_n][inner]:
+//
+//   inner > 1   one thread per output element walks the axis sequentially; neighbouring
+//               threads read neighbouring addresses, so the walk is coalesced AND keeps the
+//               reference's left-to-right accumulation order (sums are bit-identical).
+//   inner == 1  (reduction over the contiguous last axis) one workgroup per output element:
+//               strided partial accumulators per thread, then a wave shuffle + LDS tree.
+//               Sum order differs from the reference here (tolerance in the tests).
+//
+// max/min select an element, so they are exact either way; ties follow the reference:
+// complex compares the real part only, max keeps the LATER element on ties
+// (`xa.real > xb.real ? xa : xb`), complex min the EARLIER one, real min the later one.
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+namespace {
+
+template<typename T> struct alignas(2 * sizeof(T)) cx { T x, y; };
+
+template<typename R, bool CPLX> struct acc_t { R r, i; int idx; };
+
+template<typename R, bool CPLX, int OP>
+__device__ __forceinline__ acc_t<R, CPLX> acc_init() {
+    const R inf = (R) INFINITY;
+    if (OP == 2) return {-inf, -inf, -1};
+    if (OP == 3) return {inf, inf, -1};
+    return {(R) 0, (R) 0, -1};
+}
+
+// combine(a, b): a precedes b along the axis unless idx says otherwise
+template<typename R, bool CPLX, int OP>
+__device__ __forceinline__ acc_t<R, CPLX> combine(acc_t<R, CPLX> a, acc_t<R, CPLX> b) {
+    if (OP <= 1) return {a.r + b.r, a.i + b.i, 0};
+    if (b.idx < 0) return a;
+    if (a.idx < 0) return b;
+    const bool later_wins = (OP == 2) || !CPLX;
+    bool take_b;
+    if (OP == 2) take_b = b.r > a.r;
+    else         take_b = b.r < a.r;
+    if (a.r == b.r) take_b = later_wins ? (b.idx > a.idx) : (b.idx < a.idx);
+    return take_b ? b : a;
+}
+
+template<typename R, bool CPLX>
+__device__ __forceinline__ acc_t<R, CPLX> load_elem(const void *x, long long i, int idx) {
+    if (CPLX) { const cx<R> v = ((const cx<R> *) x)[i]; return {v.x, v.y, idx}; }
+    return {((const R *) x)[i], (R) 0, idx};
+}
+
+template<typename R, bool CPLX, int OP>
+__device__ __forceinline__ void store_elem(void *out, long long i, acc_t<R, CPLX> a, int axis_n) {
+    if (OP == 1) {      // dsc_mean: sum, then mul_op by (1/axis_n [, 0])   dsc.cpp:1837-1853
+        const R s = (R) 1 / (R) axis_n;
+        if (CPLX) { const R r = (a.r * s) - (a.i * (R) 0), m = (a.r * (R) 0) + (a.i * s); a.r = r; a.i = m; }
+        else      { a.r = a.r * s; }
+    }
+    if (CPLX) ((cx<R> *) out)[i] = cx<R>{a.r, a.i};
+    else      ((R *) out)[i] = a.r;
+}
+
+// one thread per output, sequential along the axis (reference order)
+template<typename R, bool CPLX, int OP>
+__global__ void reduce_seq_kernel(const void *x, void *out, long long outer, int axis_n, long long inner) {
+    const long long n_out = outer * inner;
+    for (long long o = (long long) blockIdx.x * blockDim.x + threadIdx.x; o < n_out; o += (long long) gridDim.x * blockDim.x) {
+        const long long oo = o / inner, ii = o - oo * inner;
+        const long long base = oo * axis_n * inner + ii;
+        acc_t<R, CPLX> acc = acc_init<R, CPLX, OP>();
+        for (int j = 0; j < axis_n; ++j) {
+            const acc_t<R, CPLX> v = load_elem<R, CPLX>(x, base + (long long) j * inner, j);
+            if (OP <= 1) { acc.r = acc.r + v.r; acc.i = acc.i + v.i; }
+            else acc = combine<R, CPLX, OP>(acc, v);
+        }
+        store_elem<R, CPLX, OP>(out, o, acc, axis_n);
+    }
+}
+
+template<typename R, bool CPLX>
+__device__ __forceinline__ acc_t<R, CPLX> shfl_down_acc(acc_t<R, CPLX> a, int delta) {
+    acc_t<R, CPLX> b;
+    b.r = __shfl_down(a.r, delta, 64);
+    b.i = CPLX ? __shfl_down(a.i, delta, 64) : (R) 0;
+    b.idx = __shfl_down(a.idx, delta, 64);
+    return b;
+}
+
+// one 256-thread workgroup per output row (inner == 1)
+template<typename R, bool CPLX, int OP>
+__global__ __launch_bounds__(256) void reduce_row_kernel(const void *x, void *out, long long outer, int axis_n) {
+    __shared__ acc_t<R, CPLX> part[4];
+    for (long long row = blockIdx.x; row < outer; row += gridDim.x) {
+        const long long base = row * axis_n;
+        acc_t<R, CPLX> acc = acc_init<R, CPLX, OP>();
+        for (int j = threadIdx.x; j < axis_n; j += 256)
+            acc = combine<R, CPLX, OP>(acc, load_elem<R, CPLX>(x, base + j, j));
+        for (int d = 32; d > 0; d >>= 1) acc = combine<R, CPLX, OP>(acc, shfl_down_acc<R, CPLX>(acc, d));
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            acc = combine<R, CPLX, OP>(combine<R, CPLX, OP>(part[0], part[1]), combine<R, CPLX, OP>(part[2], part[3]));
+            store_elem<R, CPLX, OP>(out, row, acc, axis_n);
+        }
+        __syncthreads();
+    }
+}
+
+template<typename R, bool CPLX, int OP>
+void launch_op(const void *x, void *out, long long outer, int axis_n, long long inner, hipStream_t s) {
+    if (inner == 1 && axis_n >= 64) {
+        long long blocks = outer < 256 * 16 ? outer : 256 * 16;
+        hipLaunchKernelGGL((reduce_row_kernel<R, CPLX, OP>), dim3((unsigned) blocks), dim3(256), 0, s, x, out, outer, axis_n);
+    } else {
+        const long long n_out = outer * inner;
+        long long blocks = (n_out + 255) / 256;
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        hipLaunchKernelGGL((reduce_seq_kernel<R, CPLX, OP>), dim3((unsigned) blocks), dim3(256), 0, s, x, out, outer, axis_n, inner);
+    }
+}
+
+template<typename R, bool CPLX>
+void launch_typed(const void *x, void *out, int op, long long outer, int axis_n, long long inner, hipStream_t s) {
+    switch (op) {
+        case 0: launch_op<R, CPLX, 0>(x, out, outer, axis_n, inner, s); break;
+        case 1: launch_op<R, CPLX, 1>(x, out, outer, axis_n, inner, s); break;
+        case 2: launch_op<R, CPLX, 2>(x, out, outer, axis_n, inner, s); break;
+        default: launch_op<R, CPLX, 3>(x, out, outer, axis_n, inner, s); break;
+    }
+}
+
+}  // namespace
+
+void dsc_launch_reduce(const void *x, void *out, int dtype, int op, long long outer, int axis_n, long long inner, hipStream_t stream) {
+    if (outer * inner <= 0) return;
+    switch (dtype) {
+        case 0: launch_typed<float, false>(x, out, op, outer, axis_n, inner, stream); break;
+        case 1: launch_typed<double, false>(x, out, op, outer, axis_n, inner, stream); break;
+        case 2: launch_typed<float, true>(x, out, op, outer, axis_n, inner, stream); break;
+        default: launch_typed<double, true>(x, out, op, outer, axis_n, inner, stream); break;
+    }
+}

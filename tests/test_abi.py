@@ -1,0 +1,81 @@
+"""CPU-only checks of the drop-in boundary: the shared library loads without a GPU and
+exports every symbol include/dsc_mi355x.h declares; the tensor struct is the reference's
+64-byte layout (dsc/include/dsc.h:96-108).  No compute call is made here."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+HEADER = os.path.join(ROOT, 'include', 'dsc_mi355x.h')
+LIB = os.path.join(ROOT, 'dsc_amd', 'libdsc_mi355x.so')
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(dsc_[a-z0-9_]+)\s*\(', src)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    if not os.path.exists(LIB):
+        subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'dsc_amd', 'csrc')])
+    return ctypes.CDLL(LIB)
+
+
+def test_header_symbols_exported(lib):
+    names = declared_symbols()
+    assert len(names) >= 36
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_python_bindings_cover_header(lib):
+    from dsc_amd import _bindings as B
+    assert sorted(B.EXPORTS) == declared_symbols()
+
+
+def test_tensor_struct_layout():
+    from dsc_amd._bindings import _DscTensor
+    assert ctypes.sizeof(_DscTensor) == 64
+    assert _DscTensor.shape.offset == 0 and _DscTensor.stride.offset == 16
+    assert _DscTensor.buffer.offset == 32 and _DscTensor.data.offset == 40
+    assert _DscTensor.ne.offset == 48 and _DscTensor.n_dim.offset == 52
+    assert _DscTensor.dtype.offset == 56 and _DscTensor.backend.offset == 57
+
+
+def test_header_is_plain_c():
+    """The boundary must be consumable from C: compile the header alone with gcc -std=c99."""
+    r = subprocess.run(['gcc', '-std=c99', '-Wall', '-Werror', '-fsyntax-only', '-x', 'c', HEADER],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_no_gpu_is_a_loud_error_not_a_fallback():
+    """Without a device, dsc_ctx_init must die (reference error convention: stderr + exit),
+    never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    code = ('import ctypes; L = ctypes.CDLL(%r); L.dsc_ctx_init.restype = ctypes.c_void_p; '
+            'L.dsc_ctx_init.argtypes = [ctypes.c_size_t] * 2; L.dsc_ctx_init(1 << 20, 1 << 20); print("ALIVE")' % LIB)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True)
+    assert r.returncode != 0 and 'ALIVE' not in r.stdout
+    assert 'no HIP device' in r.stderr or 'HIP error' in r.stderr
+
+
+def test_product_path_does_not_touch_the_oracle():
+    """oracle/ is test infrastructure: nothing under dsc_amd/ or include/ may reference it."""
+    bad = []
+    for base in ('dsc_amd', 'include'):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith(('.py', '.cpp', '.hip', '.h', 'Makefile')):
+                    txt = open(os.path.join(dp, f), errors='ignore').read()
+                    if re.search(r'\boracle\b|liboracle|libdsc_ref|/root/reference', txt):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad

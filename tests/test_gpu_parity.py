@@ -1,0 +1,194 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (ctypes, dsc_amd), against
+(1) the committed golden fixtures = outputs of the reference itself, and (2) the CPU oracle on
+seeded inputs.  Tolerance is BASELINE.json's: relative L2 <= 1e-5 for f32, 1e-12 for f64
+(tests/helpers.py:TOL), max/min exact."""
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests.helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dsc():
+    import dsc_amd
+    try:
+        dsc_amd.init(12 << 30, 4 << 30)
+    except RuntimeWarning:
+        pass
+    yield dsc_amd
+
+
+@pytest.fixture(autouse=True)
+def _sync(dsc):
+    yield
+    dsc.synchronize()
+
+
+OPS = ('fft', 'ifft', 'rfft', 'irfft')
+
+
+@pytest.mark.parametrize('group', ['fft_small', 'fft_large'])
+def test_golden_fft_family(dsc, golden, group):
+    n = 0
+    for rec, xs, y in golden.cases(group):
+        got = getattr(dsc, rec['op'])(dsc.from_numpy(xs[0]), n=rec['n'], axis=rec['axis']).numpy()
+        assert_close(got, y, what=f"{rec['key']} n={rec['n']} axis={rec['axis']} in={xs[0].shape} path={dsc.last_fft_path()}")
+        n += 1
+    assert n > 0
+
+
+def test_golden_mul(dsc, golden):
+    for rec, xs, y in golden.cases('mul'):
+        got = dsc.mul(dsc.from_numpy(xs[0]), dsc.from_numpy(xs[1])).numpy()
+        assert_close(got, y, what=rec['key'])
+
+
+def test_golden_reductions(dsc, golden):
+    for rec, xs, y in golden.cases('reduce'):
+        got = getattr(dsc, rec['op'])(dsc.from_numpy(xs[0]), axis=rec['axis'], keepdims=rec['keepdims']).numpy()
+        if rec['op'] in ('max', 'min'):
+            assert got.shape == y.shape and np.array_equal(got, y), rec['key']
+        else:
+            assert_close(got, y, what=f"{rec['key']} axis={rec['axis']}")
+
+
+def test_golden_filter_pipeline(dsc, golden):
+    """README filterFFT (README.md:113-135) as the four operator calls."""
+    for rec, xs, y in golden.cases('filter'):
+        s, b = dsc.from_numpy(xs[0]), dsc.from_numpy(xs[1])
+        S, B = dsc.rfft(s, n=rec['n']), dsc.rfft(b, n=rec['n'])
+        got = dsc.irfft(S * B).numpy()
+        assert_close(got, y, what=rec['key'])
+
+
+def test_all_axes_like_reference_test(dsc):
+    """python/tests/test_ops.py:458-489: [8,8,8,8] with the transformed axis = n, every axis,
+    crop / copy / pad through n=, forward then inverse — for f64 (as there) and f32."""
+    from oracle import port
+    rng = np.random.default_rng(42)
+    for dt, cdt in ((np.float64, np.complex128), (np.float32, np.complex64)):
+        n_ = 6
+        for axis in range(4):
+            shape = [8] * 4
+            shape[axis] = 2 ** n_
+            for change in (-1, 0, 1):
+                n = 2 ** (n_ + change)
+                x = rng.standard_normal(shape).astype(dt)
+                X = dsc.rfft(dsc.from_numpy(x), n=n, axis=axis)
+                assert_close(X.numpy(), port.rfft(x, n, axis), what=f'rfft {dt.__name__} axis={axis} n={n}')
+                assert_close(dsc.irfft(X, axis=axis).numpy(), port.irfft(port.rfft(x, n, axis), -1, axis), what='irfft')
+                xc = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(cdt)
+                F = dsc.fft(dsc.from_numpy(xc), n=n, axis=axis)
+                assert_close(F.numpy(), port.fft(xc, n, axis), what=f'fft axis={axis} n={n}')
+                assert_close(dsc.ifft(F, axis=axis).numpy(), port.ifft(port.fft(xc, n, axis), -1, axis), what='ifft')
+                # the reference's own oracle
+                assert np.allclose(X.numpy(), np.fft.rfft(x, n=n, axis=axis), atol=1e-5 if dt == np.float64 else 2e-3, rtol=1e-5)
+
+
+@pytest.mark.parametrize('N', [1, 2, 4, 8, 32, 512, 8192, 16384, 32768, 131072])
+def test_sizes_f32(dsc, N):
+    """Every kernel path: LDS (L <= 8192) and four-step (above), f32."""
+    from oracle import port
+    rng = np.random.default_rng(N)
+    rows = 3 if N <= 32768 else 2
+    x = rng.standard_normal((rows, N)).astype(np.float32)
+    if N >= 2:
+        X = dsc.rfft(dsc.from_numpy(x))
+        assert_close(X.numpy(), port.rfft(x), what=f'rfft N={N} {dsc.last_fft_path()}')
+        assert_close(dsc.irfft(X).numpy(), port.irfft(port.rfft(x)), what=f'irfft N={N} {dsc.last_fft_path()}')
+    xc = (x + 1j * rng.standard_normal(x.shape)).astype(np.complex64)
+    F = dsc.fft(dsc.from_numpy(xc))
+    assert_close(F.numpy(), port.fft(xc), what=f'fft N={N} {dsc.last_fft_path()}')
+    assert_close(dsc.ifft(F).numpy(), port.ifft(port.fft(xc)), what=f'ifft N={N}')
+
+
+@pytest.mark.parametrize('N', [16, 4096, 8192, 262144])
+def test_sizes_f64(dsc, N):
+    from oracle import port
+    rng = np.random.default_rng(N + 1)
+    x = rng.standard_normal((2, N))
+    X = dsc.rfft(dsc.from_numpy(x))
+    assert_close(X.numpy(), port.rfft(x), what=f'rfft f64 N={N} {dsc.last_fft_path()}')
+    assert_close(dsc.irfft(X).numpy(), port.irfft(port.rfft(x)), what=f'irfft f64 N={N}')
+    xc = x + 1j * rng.standard_normal(x.shape)
+    assert_close(dsc.fft(dsc.from_numpy(xc)).numpy(), port.fft(xc), what=f'fft f64 N={N}')
+
+
+def test_out_argument_and_views(dsc):
+    """`out=` is written in place and the result is a second handle on the same buffer
+    (tensor.py:160-161, dsc.cpp:399-401)."""
+    from oracle import port
+    x = np.random.default_rng(1).standard_normal((4, 256)).astype(np.float32)
+    out = dsc.empty((4, 129), dsc.Dtype.C32)
+    res = dsc.rfft(dsc.from_numpy(x), out=out)
+    assert_close(out.numpy(), port.rfft(x))
+    assert_close(res.numpy(), port.rfft(x))
+    assert res._c_ptr.contents.data == out._c_ptr.contents.data
+    assert out._c_ptr.contents.backend == 1
+
+
+def test_arena_reuse_and_double_free(dsc):
+    import dsc_amd._bindings as B
+    from dsc_amd.context import _get_ctx
+    before = dsc.used_mem()
+    t = dsc.empty((1024, 1024), dsc.Dtype.F32)
+    assert dsc.used_mem() >= before + 4 * 1024 * 1024
+    p = t._c_ptr
+    B.dsc_tensor_free(_get_ctx(), p)
+    B.dsc_tensor_free(_get_ctx(), p)          # tolerated, as the reference's allocator does
+    del t
+    assert dsc.used_mem() == before
+
+
+def test_mul_broadcast_and_scalars(dsc):
+    from oracle import port
+    rng = np.random.default_rng(9)
+    a = (rng.standard_normal((64, 513)) + 1j * rng.standard_normal((64, 513))).astype(np.complex64)
+    h = (rng.standard_normal(513) + 1j * rng.standard_normal(513)).astype(np.complex64)
+    assert_close((dsc.from_numpy(a) * dsc.from_numpy(h)).numpy(), port.mul(a, h))
+    assert_close((dsc.from_numpy(a) * 2.5).numpy(), port.mul(a, np.array([2.5], np.float32).astype(np.complex64)))
+    assert_close((3 * dsc.from_numpy(a)).numpy(), port.mul(np.array([3], np.complex64), a))
+    assert_close((dsc.from_numpy(a) * (1 + 2j)).numpy(), port.mul(a, np.array([1 + 2j], np.complex64)))
+    d = rng.standard_normal((64, 513))
+    assert (dsc.from_numpy(d) * dsc.from_numpy(a)).dtype == dsc.Dtype.C32       # F64 x C32 -> C32
+
+
+def test_reduce_large_rows(dsc):
+    """Row-reduction kernel (inner == 1, tree order) and sequential kernel on bigger inputs."""
+    from oracle import port
+    rng = np.random.default_rng(10)
+    for dt in (np.float32, np.complex64, np.float64):
+        x = rng.standard_normal((37, 5000)).astype(dt)
+        if np.dtype(dt).kind == 'c':
+            x = (x + 1j * rng.standard_normal(x.shape)).astype(dt)
+        for axis in (0, 1):
+            for name, op in (('sum', port.SUM), ('mean', port.MEAN)):
+                got = getattr(dsc, name)(dsc.from_numpy(x), axis=axis).numpy()
+                want = port.reduce(x, op, axis, True)
+                tol = 2e-5 if dt != np.float64 else 1e-12     # different summation order on axis=1
+                assert np.max(np.abs(got - want)) <= tol * np.max(np.abs(x)) * np.sqrt(x.shape[axis]), (name, dt, axis)
+            xq = (np.round(x.real * 4) / 4 + (1j * x.imag if np.dtype(dt).kind == 'c' else 0)).astype(dt)
+            for name, op in (('max', port.MAX), ('min', port.MIN)):
+                got = getattr(dsc, name)(dsc.from_numpy(xq), axis=axis, keepdims=False).numpy()
+                assert np.array_equal(got, port.reduce(xq, op, axis, False)), (name, dt, axis)
+
+
+def test_errors_abort_like_the_reference():
+    """Invalid arguments print and exit(EXIT_FAILURE) (dsc.h:14-28): rfft of a complex tensor
+    (dsc.cpp:2211), irfft of a real one (:2215), shape mismatch of `out` (:2221-2223)."""
+    cases = {
+        'rfft_complex': 'dsc.rfft(dsc.from_numpy(np.ones(8, np.complex64)))',
+        'irfft_real': 'dsc.irfft(dsc.from_numpy(np.ones(9, np.float32)))',
+        'bad_out': 'dsc.rfft(dsc.from_numpy(np.ones(8, np.float32)), out=dsc.empty((4,), dsc.Dtype.C32))',
+        'no_broadcast': 'dsc.mul(dsc.from_numpy(np.ones((2, 3), np.float32)), dsc.from_numpy(np.ones((2, 4), np.float32)))',
+    }
+    for name, stmt in cases.items():
+        code = f'import numpy as np, dsc_amd as dsc\ndsc.init(1 << 26, 1 << 26)\n{stmt}\ndsc.synchronize()\nprint("SURVIVED")'
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True)
+        assert r.returncode != 0 and 'SURVIVED' not in r.stdout, (name, r.stdout, r.stderr)
+        assert 'RFFT input must be real' in r.stderr or 'IRFFT input must be complex' in r.stderr or 'DSC_ASSERT' in r.stderr, name
