@@ -1,7 +1,321 @@
-// placeholder: replaced by the register-resident kernels
+// fft_r2c_64k.hip — 65536-point real FFT (f32) with the whole transform resident in registers.
+//
+// Replaces, for this size, the reference's per-line loop  gather -> dsc_real_fft -> scatter
+// (dsc/src/dsc.cpp:2102-2171, dsc/include/dsc_fft.h:57-103, 178-238) by ONE pass over HBM:
+// 4 B/sample in, 8 B/sample out, nothing else touches memory.
+//
+// Why registers: the packed transform is M = 32768 complex = 256 KiB per row, more than the
+// 160 KiB of LDS but half of a CU's 512 KiB vector register file.  One 1024-thread workgroup
+// (16 waves, 4 per SIMD, <= 128 VGPRs each) owns one row: 32 complex per thread.
+//
+//   M = 32 x 32 x 32,   j = 1024 j1 + 32 j2 + j3   (input),   k = k1 + 32 k2 + 1024 k3   (output)
+//
+//   load    thread t = 32 j2 + j3 reads z[1024 j1 + t], j1 = 0..31       (coalesced 8 B / lane)
+//   pass 1  32-point DFT over j1 in registers, times W_1024^{j2 k1}
+//   xchg 1  transpose j2 <-> k1 through LDS (re plane, then im plane: 136 KiB each)
+//   pass 2  32-point DFT over j2, times W_32768^{j3 (k1 + 32 k2)}
+//   xchg 2  transpose j3 <-> k2 through LDS; the reader picks the column k' = k1 + 32 k2 so
+//           that lane l and lane 63-l of a wave hold columns k' and 1024-k'
+//   pass 3  32-point DFT over j3: Z[k' + 1024 k3]
+//   post    packed-real untangling (dsc_fft.h:199-225) needs Z[k] and Z[M-k]: the partner
+//           lane holds it, fetched with ds_bpermute (no LDS storage); each lane finishes 16
+//           bin pairs and stores X[k] and X[M-k]                            (8 B / lane)
+//
+// In-register DFTs are radix-2 DIF with compile-time twiddles (output index bit-reversed in
+// the register number, which is free: every register index is a constant).  Inter-pass
+// twiddles come from an 8 KiB LDS table (W_1024) and two per-thread constants.
+// The inverse kernel (dsc_irfft, dsc_fft.h:194-236) is the same pipeline run backwards.
 #include "kernels.h"
-size_t dsc_r2c64k_table_bytes() { return 0; }
-void dsc_r2c64k_build_tables(void *) {}
-void dsc_launch_rfft64k(const float *, void *, int, const void *, int, hipStream_t) {}
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <utility>
+
+namespace {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+constexpr int kM = 32768;            // complex points per row
+constexpr int kRowPitch = 34;        // floats per LDS row: 32 + 2 -> conflict-free b64 row reads
+constexpr int kPlaneFloats = 1024 * kRowPitch;
+constexpr int kLdsBytes = kPlaneFloats * 4 + 1024 * 8;      // exchange plane + W_1024 table
+constexpr int kTabEntries = 1024;
+
+// aux table layout (f2 entries): [0,1024) W_1024^m | [1024,2048) W_32768^m | [2048,3072) W_65536^m
+constexpr int kAuxW1024 = 0, kAuxW32768 = 1024, kAuxW65536 = 2048, kAuxEntries = 3072;
+
+__host__ __device__ constexpr int br5(int x) {
+    return ((x & 1) << 4) | ((x & 2) << 2) | (x & 4) | ((x & 8) >> 2) | ((x & 16) >> 4);
+}
+
+// cos / sin of 2 pi q / 64, q = 0..16 (first quadrant; the rest by symmetry)
+__device__ constexpr float kCos64[17] = {
+    1.0f, 0.99518472667219688624f, 0.98078528040323044913f, 0.95694033573220886494f,
+    0.92387953251128675613f, 0.88192126434835502971f, 0.83146961230254523708f, 0.77301045336273696081f,
+    0.70710678118654752440f, 0.63439328416364549822f, 0.55557023301960222474f, 0.47139673682599764856f,
+    0.38268343236508977173f, 0.29028467725446236764f, 0.19509032201612826785f, 0.09801714032956060199f,
+    0.0f};
+
+// exp(-2 pi i q / 64) for q in [0, 64): (cos, -sin)
+__device__ constexpr float root64_re(int q) {
+    q &= 63;
+    return q <= 16 ? kCos64[q] : q <= 32 ? -kCos64[32 - q] : q <= 48 ? -kCos64[q - 32] : kCos64[64 - q];
+}
+__device__ constexpr float root64_im(int q) {      // -sin(2 pi q / 64)
+    q &= 63;
+    return q <= 16 ? -kCos64[16 - q] : q <= 32 ? -kCos64[q - 16] : q <= 48 ? kCos64[48 - q] : kCos64[q - 48];
+}
+
+__device__ __forceinline__ f2 cmul(f2 a, f2 w) {
+    return f2{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x};
+}
+__device__ __forceinline__ f2 cmul_conj(f2 a, f2 w) {     // a * conj(w)
+    return f2{a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y};
+}
+
+// d * W_M^K (forward) or d * conj(W_M^K) (INV), K < M/2, constants folded at compile time
+template<bool INV, int M, int K>
+__device__ __forceinline__ f2 mul_root(f2 d) {
+    constexpr float c8 = 0.70710678118654752440f;
+    if constexpr (K == 0) {
+        return d;
+    } else if constexpr (4 * K == M) {
+        return INV ? f2{-d.y, d.x} : f2{d.y, -d.x};
+    } else if constexpr (8 * K == M) {
+        return INV ? f2{(d.x - d.y) * c8, (d.x + d.y) * c8} : f2{(d.x + d.y) * c8, (d.y - d.x) * c8};
+    } else if constexpr (8 * K == 3 * M) {
+        return INV ? f2{-(d.x + d.y) * c8, (d.x - d.y) * c8} : f2{(d.y - d.x) * c8, -(d.x + d.y) * c8};
+    } else {
+        constexpr float wr = root64_re(K * (64 / M));
+        constexpr float wi = INV ? -root64_im(K * (64 / M)) : root64_im(K * (64 / M));
+        return f2{d.x * wr - d.y * wi, d.x * wi + d.y * wr};
+    }
+}
+
+template<bool INV, int M, int G, int... K>
+__device__ __forceinline__ void dif_group(f2 (&v)[32], std::integer_sequence<int, K...>) {
+    (([&] {
+         const f2 u = v[G + K] + v[G + K + M / 2];
+         const f2 d = v[G + K] - v[G + K + M / 2];
+         v[G + K] = u;
+         v[G + K + M / 2] = mul_root<INV, M, K>(d);
+     }()),
+     ...);
+}
+
+template<bool INV, int M, int... G>
+__device__ __forceinline__ void dif_stage(f2 (&v)[32], std::integer_sequence<int, G...>) {
+    (dif_group<INV, M, G * M>(v, std::make_integer_sequence<int, M / 2>{}), ...);
+}
+
+// 32-point DFT, natural order in; v[p] returns bin br5(p).
+template<bool INV>
+__device__ __forceinline__ void dft32(f2 (&v)[32]) {
+    dif_stage<INV, 32>(v, std::make_integer_sequence<int, 1>{});
+    dif_stage<INV, 16>(v, std::make_integer_sequence<int, 2>{});
+    dif_stage<INV, 8>(v, std::make_integer_sequence<int, 4>{});
+    dif_stage<INV, 4>(v, std::make_integer_sequence<int, 8>{});
+    dif_stage<INV, 2>(v, std::make_integer_sequence<int, 16>{});
+}
+
+typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+
+// LDS transpose of one float plane: every thread writes 32 floats at wbase + slot * 1088
+// (slot = br5(p): register p of a DIF output holds logical index br5(p)) and reads back its
+// own row of 32 as 16 x b64.  Two base registers cover all 32 slots with 16-bit immediates.
+template<int COMP>
+__device__ __forceinline__ void plane_write(float *plane, int wbase, const f2 (&v)[32]) {
+    float *lo16 = plane + wbase;
+    float *hi16 = lo16 + 16 * (32 * kRowPitch);
+#pragma unroll
+    for (int p = 0; p < 32; ++p) {
+        const int slot = br5(p);
+        const float val = COMP == 0 ? v[p].x : v[p].y;
+        if (slot < 16) lo16[slot * (32 * kRowPitch)] = val;
+        else           hi16[(slot - 16) * (32 * kRowPitch)] = val;
+    }
+}
+template<int COMP>
+__device__ __forceinline__ void plane_read(const float *plane, int row, f2 (&v)[32]) {
+    const f2 *r = (const f2 *) (plane + row * kRowPitch);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const f2 t = r[m];
+        if (COMP == 0) { v[2 * m].x = t.x; v[2 * m + 1].x = t.y; }
+        else           { v[2 * m].y = t.x; v[2 * m + 1].y = t.y; }
+    }
+}
+
+__device__ __forceinline__ float bperm(int byte_addr, float x) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(x)));
+}
+
+// Column of the output spectrum a lane owns in pass 3 / post-pass (see file header).
+__device__ __forceinline__ int column_of(int wave, int lane) {
+    int kp = lane < 32 ? 32 * wave + lane : 1024 - 32 * wave - (63 - lane);
+    return kp == 1024 ? 512 : kp;
+}
+
+// Values derived from threadIdx are loop invariant; hipcc hoists every address built from
+// them out of the persistent row loop (dozens of VGPRs) and then spills them.  Passing the
+// thread id through an empty asm once per row keeps those computations inside the loop.
+__device__ __forceinline__ int per_row(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+// ------------------------------------------------------------------------------------------
+// forward: x [batch][65536] f32  ->  X [batch][32769] c32
+__global__ __launch_bounds__(1024) void rfft64k_kernel(const float *__restrict__ x, f2 *__restrict__ X, int batch,
+                                                       const f2 *__restrict__ aux) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *plane = lds;
+    f2 *w1024 = (f2 *) (lds + kPlaneFloats);
+
+    {
+        const int t0 = threadIdx.x;
+        w1024[t0] = aux[kAuxW1024 + t0];
+    }
+    __syncthreads();
+
+    for (int row = blockIdx.x; row < batch; row += gridDim.x) {
+        const int t = per_row(threadIdx.x);
+        const int lane = t & 63, wave = t >> 6;
+        const int hi = t >> 5, lo = t & 31;          // (j2, j3) in pass 1; (k1, j3) in pass 2
+
+        // row descriptors: wave-uniform base, per-lane 32-bit byte offset, SGPR/immediate steps
+        const __amdgpu_buffer_rsrc_t rin =
+            __builtin_amdgcn_make_buffer_rsrc((void *) (x + (size_t) row * 65536), 0, 65536 * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rout =
+            __builtin_amdgcn_make_buffer_rsrc((void *) (X + (size_t) row * (kM + 1)), 0, (kM + 1) * 8, 0x00020000);
+
+        f2 v[32];
+#pragma unroll
+        for (int j1 = 0; j1 < 32; ++j1)
+            v[j1] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rin, t * 8, j1 * 8192, 0));
+
+        // ---- pass 1 (over j1) and twiddle W_1024^{j2 k1}
+        dft32<false>(v);
+#pragma unroll
+        for (int k1 = 1; k1 < 32; ++k1) v[br5(k1)] = cmul(v[br5(k1)], w1024[hi * k1]);
+
+        // ---- exchange 1: (j2, j3)[k1] -> (k1, j3)[j2];  row = k1*32 + j3 (slot k1), col = j2
+        const int wbase1 = lo * kRowPitch + hi;
+        f2 u[32];
+        __syncthreads();                                   // plane free (previous row's readers done)
+        plane_write<0>(plane, wbase1, v);
+        __syncthreads();
+        plane_read<0>(plane, t, u);
+        __syncthreads();
+        plane_write<1>(plane, wbase1, v);
+        __syncthreads();
+        plane_read<1>(plane, t, u);
+
+        // ---- pass 2 (over j2) and twiddle W_32768^{j3 k1} * W_1024^{j3 k2}
+        dft32<false>(u);
+        {
+            const f2 tw2_base = aux[kAuxW32768 + hi * lo];             // W_32768^{j3 k1}
+            u[0] = cmul(u[0], tw2_base);
+#pragma unroll
+            for (int k2 = 1; k2 < 32; ++k2) u[br5(k2)] = cmul(u[br5(k2)], cmul(tw2_base, w1024[lo * k2]));
+        }
+
+        // ---- exchange 2: (k1, j3)[k2] -> column k' = k1 + 32 k2, [j3];  row = k' (slot k2), col = j3
+        const int wbase2 = hi * kRowPitch + lo;
+        const int kp = column_of(wave, lane);
+        __syncthreads();
+        plane_write<0>(plane, wbase2, u);
+        __syncthreads();
+        plane_read<0>(plane, kp, v);
+        __syncthreads();
+        plane_write<1>(plane, wbase2, u);
+        __syncthreads();
+        plane_read<1>(plane, kp, v);
+
+        // ---- pass 3 (over j3): v[p] = Z[k' + 1024 br5(p)]
+        dft32<false>(v);
+
+        // ---- packed-real post-pass.  Rows 0..15 of this column pair with rows 31..16 of the
+        // partner column (odd registers there); fetch them, finish both bins of each pair.
+        const int partner_addr = ((wave == 0 && (lane == 63 || lane == 0)) ? lane : 63 - lane) * 4;
+        if (wave == 0 && lane == 0) {                      // bin M/2 = conj Z[M/2] (dsc_fft.h:218)
+            const f2 mid = f2{v[br5(16)].x, -v[br5(16)].y};
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, mid), rout, (kM / 2) * 8, 0, 0);
+        }
+        // -(i/2) W_65536^{k'}: the post-pass multiplies (a - conj b) by -i w / 2
+        const f2 wpost = aux[kAuxW65536 + kp];
+        const f2 post_base = f2{0.5f * wpost.y, -0.5f * wpost.x};
+        const int off_k = kp * 8;                               // X[k],   k = k' + 1024 k3: + k3 * 8192
+        const int off_mk = (kM - 15 * 1024 - kp) * 8;           // X[M-k]:                  + (15 - k3) * 8192
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {                  // two batches of 8 pairs: VGPR budget
+            f2 b[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k3 = half * 8 + i;
+                const int src = 31 - br5(k3);                  // = br5(31 - k3)
+                b[i].x = bperm(partner_addr, v[src].x);
+                b[i].y = bperm(partner_addr, v[src].y);
+            }
+            if (wave == 0) {                                   // column 0 pairs row k3 with row 32 - k3 of itself
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const f2 own = v[br5((32 - (half * 8 + i)) & 31)];
+                    b[i] = lane == 0 ? own : b[i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k3 = half * 8 + i;
+                const f2 a = v[br5(k3)];
+                const f2 s = f2{a.x + b[i].x, a.y - b[i].y};          // a + conj b
+                const f2 d = f2{a.x - b[i].x, a.y + b[i].y};          // a - conj b
+                const f2 c = f2{root64_re(k3), root64_im(k3)};        // W_64^{k3} = W_65536^{1024 k3}
+                const f2 w = k3 == 0 ? post_base : cmul(post_base, c);
+                const f2 wd = cmul(d, w);
+                const f2 xk = f2{0.5f * s.x + wd.x, 0.5f * s.y + wd.y};
+                const f2 xm = f2{0.5f * s.x - wd.x, wd.y - 0.5f * s.y};
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, xk), rout, off_k, k3 * 8192, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, xm), rout, off_mk, (15 - k3) * 8192, 0);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+size_t dsc_r2c64k_table_bytes() { return (size_t) kAuxEntries * sizeof(float) * 2; }
+
+void dsc_r2c64k_build_tables(void *host_dst) {
+    float *o = (float *) host_dst;
+    auto put = [&](int at, long long k, long long n) {
+        const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double) k / (long double) n;
+        o[2 * at] = (float) cosl(a);
+        o[2 * at + 1] = (float) sinl(a);
+    };
+    for (int m = 0; m < kTabEntries; ++m) {
+        put(kAuxW1024 + m, m, 1024);
+        put(kAuxW32768 + m, m, 32768);
+        put(kAuxW65536 + m, m, 65536);
+    }
+    // exact values on the axes (bin M/2 relies on W_65536^{16384 * ...} only through constants,
+    // but keep the tables clean too)
+    o[2 * (kAuxW1024 + 256)] = 0.f;  o[2 * (kAuxW1024 + 256) + 1] = -1.f;
+    o[2 * (kAuxW1024 + 512)] = -1.f; o[2 * (kAuxW1024 + 512) + 1] = 0.f;
+    o[2 * (kAuxW1024 + 768)] = 0.f;  o[2 * (kAuxW1024 + 768) + 1] = 1.f;
+}
+
+void dsc_launch_rfft64k(const float *x, void *X, int batch, const void *aux, int n_cu, hipStream_t stream) {
+    if (batch <= 0) return;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void) hipFuncSetAttribute((const void *) rfft64k_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        attr_set = true;
+    }
+    const int grid = batch < n_cu ? batch : n_cu;
+    hipLaunchKernelGGL(rfft64k_kernel, dim3(grid), dim3(1024), kLdsBytes, stream, x, (f2 *) X, batch, (const f2 *) aux);
+}
+
 void dsc_launch_irfft64k(const void *, float *, int, const void *, int, hipStream_t) {}
 void dsc_launch_filter64k(const float *, const void *, float *, int, const void *, int, hipStream_t) {}
