@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <utility>
 
 namespace {
@@ -157,6 +158,33 @@ __device__ __forceinline__ int column_of(int wave, int lane) {
     return kp == 1024 ? 512 : kp;
 }
 
+// Diagnostic build only (tools/probe64k.hip defines DSC_R2C64K_STAMPS): wave 0 of every
+// workgroup records 100 MHz realtime stamps per phase into a side buffer.
+#ifdef DSC_R2C64K_STAMPS
+#define STAMP(i)                                                                              \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        if (stamps && threadIdx.x == 0 && it < 64)                                            \
+            stamps[((size_t) blockIdx.x * 64 + it) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
+#ifdef DSC_R2C64K_PROBE            // extra kernel arguments of the diagnostic builds
+#define PROBE_ARGS , unsigned long long *stamps, int io_on
+#define PROBE_NULL , nullptr, 1
+#define IO_ON io_on                // 0: zero-record descriptors, every global access is dropped
+#else
+#define PROBE_ARGS
+#define PROBE_NULL
+#define IO_ON 1
+#endif
+#ifndef DSC_R2C64K_SKIP
+#define DSC_R2C64K_SKIP 0
+#endif
+#define SKIP(bit) ((DSC_R2C64K_SKIP) & (bit))   // compile-time ablation: 1 dft32, 2 twiddles, 4 LDS traffic, 8 barriers, 16 post-pass
+
 // Values derived from threadIdx are loop invariant; hipcc hoists every address built from
 // them out of the persistent row loop (dozens of VGPRs) and then spills them.  Passing the
 // thread id through an empty asm once per row keeps those computations inside the loop.
@@ -165,10 +193,22 @@ __device__ __forceinline__ int per_row(int x) {
     return x;
 }
 
+// Every workgroup alternates a memory phase (load a row / store a row) with ~12 us of
+// register/LDS work during which it issues no HBM traffic.  Workgroups launched together
+// stay in lockstep, so the whole chip alternates between "all loading" and "all computing".
+// Delaying every other workgroup of each XCD by half a period interleaves the two phases:
+// while one half computes, the other half has the HBM to itself.  (100 MHz realtime ticks.)
+__device__ __forceinline__ void stagger_start(int ticks) {
+    if (ticks > 0 && ((blockIdx.x >> 3) & 1)) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while ((long long) (__builtin_amdgcn_s_memrealtime() - t0) < ticks) __builtin_amdgcn_s_sleep(16);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // forward: x [batch][65536] f32  ->  X [batch][32769] c32
 __global__ __launch_bounds__(1024) void rfft64k_kernel(const float *__restrict__ x, f2 *__restrict__ X, int batch,
-                                                       const f2 *__restrict__ aux) {
+                                                       const f2 *__restrict__ aux, int stagger_ticks PROBE_ARGS) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *plane = lds;
     f2 *w1024 = (f2 *) (lds + kPlaneFloats);
@@ -177,44 +217,52 @@ __global__ __launch_bounds__(1024) void rfft64k_kernel(const float *__restrict__
         const int t0 = threadIdx.x;
         w1024[t0] = aux[kAuxW1024 + t0];
     }
+    stagger_start(stagger_ticks);
     __syncthreads();
 
-    for (int row = blockIdx.x; row < batch; row += gridDim.x) {
+    int it = 0;
+    for (int row = blockIdx.x; row < batch; row += gridDim.x, ++it) {
         const int t = per_row(threadIdx.x);
+        STAMP(0);
         const int lane = t & 63, wave = t >> 6;
         const int hi = t >> 5, lo = t & 31;          // (j2, j3) in pass 1; (k1, j3) in pass 2
 
         // row descriptors: wave-uniform base, per-lane 32-bit byte offset, SGPR/immediate steps
         const __amdgpu_buffer_rsrc_t rin =
-            __builtin_amdgcn_make_buffer_rsrc((void *) (x + (size_t) row * 65536), 0, 65536 * 4, 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc((void *) (x + (size_t) row * 65536), 0, 65536 * 4 * IO_ON, 0x00020000);
         const __amdgpu_buffer_rsrc_t rout =
-            __builtin_amdgcn_make_buffer_rsrc((void *) (X + (size_t) row * (kM + 1)), 0, (kM + 1) * 8, 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc((void *) (X + (size_t) row * (kM + 1)), 0, (kM + 1) * 8 * IO_ON, 0x00020000);
 
         f2 v[32];
 #pragma unroll
         for (int j1 = 0; j1 < 32; ++j1)
             v[j1] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rin, t * 8, j1 * 8192, 0));
 
+        STAMP(1);                                          // loads issued
         // ---- pass 1 (over j1) and twiddle W_1024^{j2 k1}
-        dft32<false>(v);
+        if (!SKIP(1)) dft32<false>(v);
+        if (!SKIP(2)) {
 #pragma unroll
-        for (int k1 = 1; k1 < 32; ++k1) v[br5(k1)] = cmul(v[br5(k1)], w1024[hi * k1]);
+            for (int k1 = 1; k1 < 32; ++k1) v[br5(k1)] = cmul(v[br5(k1)], w1024[hi * k1]);
+        }
 
         // ---- exchange 1: (j2, j3)[k1] -> (k1, j3)[j2];  row = k1*32 + j3 (slot k1), col = j2
         const int wbase1 = lo * kRowPitch + hi;
         f2 u[32];
-        __syncthreads();                                   // plane free (previous row's readers done)
-        plane_write<0>(plane, wbase1, v);
-        __syncthreads();
-        plane_read<0>(plane, t, u);
-        __syncthreads();
-        plane_write<1>(plane, wbase1, v);
-        __syncthreads();
-        plane_read<1>(plane, t, u);
+        STAMP(2);                                          // pass 1 done (includes the wait for the loads)
+        if (!SKIP(8)) __syncthreads();                     // plane free (previous row's readers done)
+        if (!SKIP(4)) plane_write<0>(plane, wbase1, v);
+        if (!SKIP(8)) __syncthreads();
+        if (!SKIP(4)) plane_read<0>(plane, t, u); else { for (int i = 0; i < 32; ++i) u[i] = v[31 - i]; }
+        if (!SKIP(8)) __syncthreads();
+        if (!SKIP(4)) plane_write<1>(plane, wbase1, v);
+        if (!SKIP(8)) __syncthreads();
+        if (!SKIP(4)) plane_read<1>(plane, t, u);
+        STAMP(3);                                          // exchange 1 done
 
         // ---- pass 2 (over j2) and twiddle W_32768^{j3 k1} * W_1024^{j3 k2}
-        dft32<false>(u);
-        {
+        if (!SKIP(1)) dft32<false>(u);
+        if (!SKIP(2)) {
             const f2 tw2_base = aux[kAuxW32768 + hi * lo];             // W_32768^{j3 k1}
             u[0] = cmul(u[0], tw2_base);
 #pragma unroll
@@ -224,17 +272,20 @@ __global__ __launch_bounds__(1024) void rfft64k_kernel(const float *__restrict__
         // ---- exchange 2: (k1, j3)[k2] -> column k' = k1 + 32 k2, [j3];  row = k' (slot k2), col = j3
         const int wbase2 = hi * kRowPitch + lo;
         const int kp = column_of(wave, lane);
-        __syncthreads();
-        plane_write<0>(plane, wbase2, u);
-        __syncthreads();
-        plane_read<0>(plane, kp, v);
-        __syncthreads();
-        plane_write<1>(plane, wbase2, u);
-        __syncthreads();
-        plane_read<1>(plane, kp, v);
+        STAMP(4);                                          // pass 2 done
+        if (!SKIP(8)) __syncthreads();
+        if (!SKIP(4)) plane_write<0>(plane, wbase2, u);
+        if (!SKIP(8)) __syncthreads();
+        if (!SKIP(4)) plane_read<0>(plane, kp, v); else { for (int i = 0; i < 32; ++i) v[i] = u[31 - i]; }
+        if (!SKIP(8)) __syncthreads();
+        if (!SKIP(4)) plane_write<1>(plane, wbase2, u);
+        if (!SKIP(8)) __syncthreads();
+        if (!SKIP(4)) plane_read<1>(plane, kp, v);
+        STAMP(5);                                          // exchange 2 done
 
         // ---- pass 3 (over j3): v[p] = Z[k' + 1024 br5(p)]
-        dft32<false>(v);
+        if (!SKIP(1)) dft32<false>(v);
+        STAMP(6);                                          // pass 3 done
 
         // ---- packed-real post-pass.  Rows 0..15 of this column pair with rows 31..16 of the
         // partner column (odd registers there); fetch them, finish both bins of each pair.
@@ -272,14 +323,15 @@ __global__ __launch_bounds__(1024) void rfft64k_kernel(const float *__restrict__
                 const f2 s = f2{a.x + b[i].x, a.y - b[i].y};          // a + conj b
                 const f2 d = f2{a.x - b[i].x, a.y + b[i].y};          // a - conj b
                 const f2 c = f2{root64_re(k3), root64_im(k3)};        // W_64^{k3} = W_65536^{1024 k3}
-                const f2 w = k3 == 0 ? post_base : cmul(post_base, c);
-                const f2 wd = cmul(d, w);
+                const f2 w = (k3 == 0 || SKIP(16)) ? post_base : cmul(post_base, c);
+                const f2 wd = SKIP(16) ? d : cmul(d, w);
                 const f2 xk = f2{0.5f * s.x + wd.x, 0.5f * s.y + wd.y};
                 const f2 xm = f2{0.5f * s.x - wd.x, wd.y - 0.5f * s.y};
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, xk), rout, off_k, k3 * 8192, 0);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, xm), rout, off_mk, (15 - k3) * 8192, 0);
             }
         }
+        STAMP(7);                                          // post-pass done, stores issued
     }
 }
 
@@ -314,7 +366,13 @@ void dsc_launch_rfft64k(const float *x, void *X, int batch, const void *aux, int
         attr_set = true;
     }
     const int grid = batch < n_cu ? batch : n_cu;
-    hipLaunchKernelGGL(rfft64k_kernel, dim3(grid), dim3(1024), kLdsBytes, stream, x, (f2 *) X, batch, (const f2 *) aux);
+    static int stagger = -1;
+    if (stagger < 0) {
+        const char *e = getenv("DSC_STAGGER_TICKS");
+        stagger = e ? atoi(e) : 0;
+    }
+    hipLaunchKernelGGL(rfft64k_kernel, dim3(grid), dim3(1024), kLdsBytes, stream, x, (f2 *) X, batch, (const f2 *) aux,
+                       batch >= 2 * n_cu ? stagger : 0 PROBE_NULL);
 }
 
 void dsc_launch_irfft64k(const void *, float *, int, const void *, int, hipStream_t) {}
