@@ -35,7 +35,17 @@
 
 namespace {
 
-typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f2 __attribute__((ext_vector_type(2)));      // memory-op type only (8-B loads / stores / LDS)
+
+// Arithmetic is done on plain scalar pairs, and this file is built with -fno-slp-vectorize:
+// v_pk_*_f32 issues at half the rate of the scalar forms on gfx950 (measured, tools/valubench.hip:
+// ~6 vs ~3 cycles per wave-instruction), cannot take literal constants (every twiddle constant
+// would occupy a VGPR pair for the whole kernel) and needs v_mov shuffles to line operands up.
+struct cf { float x, y; };
+__device__ __forceinline__ cf operator+(cf a, cf b) { return cf{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cf operator-(cf a, cf b) { return cf{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cf to_cf(f2 a) { return cf{a.x, a.y}; }
+__device__ __forceinline__ f2 to_f2(cf a) { return f2{a.x, a.y}; }
 
 constexpr int kM = 32768;            // complex points per row
 constexpr int kRowPitch = 34;        // floats per LDS row: 32 + 2 -> conflict-free b64 row reads
@@ -68,37 +78,37 @@ __device__ constexpr float root64_im(int q) {      // -sin(2 pi q / 64)
     return q <= 16 ? -kCos64[16 - q] : q <= 32 ? -kCos64[q - 16] : q <= 48 ? kCos64[48 - q] : kCos64[q - 48];
 }
 
-__device__ __forceinline__ f2 cmul(f2 a, f2 w) {
-    return f2{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x};
+__device__ __forceinline__ cf cmul(cf a, cf w) {
+    return cf{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x};
 }
-__device__ __forceinline__ f2 cmul_conj(f2 a, f2 w) {     // a * conj(w)
-    return f2{a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y};
+__device__ __forceinline__ cf cmul_conj(cf a, cf w) {     // a * conj(w)
+    return cf{a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y};
 }
 
 // d * W_M^K (forward) or d * conj(W_M^K) (INV), K < M/2, constants folded at compile time
 template<bool INV, int M, int K>
-__device__ __forceinline__ f2 mul_root(f2 d) {
+__device__ __forceinline__ cf mul_root(cf d) {
     constexpr float c8 = 0.70710678118654752440f;
     if constexpr (K == 0) {
         return d;
     } else if constexpr (4 * K == M) {
-        return INV ? f2{-d.y, d.x} : f2{d.y, -d.x};
+        return INV ? cf{-d.y, d.x} : cf{d.y, -d.x};
     } else if constexpr (8 * K == M) {
-        return INV ? f2{(d.x - d.y) * c8, (d.x + d.y) * c8} : f2{(d.x + d.y) * c8, (d.y - d.x) * c8};
+        return INV ? cf{(d.x - d.y) * c8, (d.x + d.y) * c8} : cf{(d.x + d.y) * c8, (d.y - d.x) * c8};
     } else if constexpr (8 * K == 3 * M) {
-        return INV ? f2{-(d.x + d.y) * c8, (d.x - d.y) * c8} : f2{(d.y - d.x) * c8, -(d.x + d.y) * c8};
+        return INV ? cf{-(d.x + d.y) * c8, (d.x - d.y) * c8} : cf{(d.y - d.x) * c8, -(d.x + d.y) * c8};
     } else {
         constexpr float wr = root64_re(K * (64 / M));
         constexpr float wi = INV ? -root64_im(K * (64 / M)) : root64_im(K * (64 / M));
-        return f2{d.x * wr - d.y * wi, d.x * wi + d.y * wr};
+        return cf{d.x * wr - d.y * wi, d.x * wi + d.y * wr};
     }
 }
 
 template<bool INV, int M, int G, int... K>
-__device__ __forceinline__ void dif_group(f2 (&v)[32], std::integer_sequence<int, K...>) {
+__device__ __forceinline__ void dif_group(cf (&v)[32], std::integer_sequence<int, K...>) {
     (([&] {
-         const f2 u = v[G + K] + v[G + K + M / 2];
-         const f2 d = v[G + K] - v[G + K + M / 2];
+         const cf u = v[G + K] + v[G + K + M / 2];
+         const cf d = v[G + K] - v[G + K + M / 2];
          v[G + K] = u;
          v[G + K + M / 2] = mul_root<INV, M, K>(d);
      }()),
@@ -106,13 +116,13 @@ __device__ __forceinline__ void dif_group(f2 (&v)[32], std::integer_sequence<int
 }
 
 template<bool INV, int M, int... G>
-__device__ __forceinline__ void dif_stage(f2 (&v)[32], std::integer_sequence<int, G...>) {
+__device__ __forceinline__ void dif_stage(cf (&v)[32], std::integer_sequence<int, G...>) {
     (dif_group<INV, M, G * M>(v, std::make_integer_sequence<int, M / 2>{}), ...);
 }
 
 // 32-point DFT, natural order in; v[p] returns bin br5(p).
 template<bool INV>
-__device__ __forceinline__ void dft32(f2 (&v)[32]) {
+__device__ __forceinline__ void dft32(cf (&v)[32]) {
     dif_stage<INV, 32>(v, std::make_integer_sequence<int, 1>{});
     dif_stage<INV, 16>(v, std::make_integer_sequence<int, 2>{});
     dif_stage<INV, 8>(v, std::make_integer_sequence<int, 4>{});
@@ -121,12 +131,14 @@ __device__ __forceinline__ void dft32(f2 (&v)[32]) {
 }
 
 typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 
 // LDS transpose of one float plane: every thread writes 32 floats at wbase + slot * 1088
 // (slot = br5(p): register p of a DIF output holds logical index br5(p)) and reads back its
 // own row of 32 as 16 x b64.  Two base registers cover all 32 slots with 16-bit immediates.
 template<int COMP>
-__device__ __forceinline__ void plane_write(float *plane, int wbase, const f2 (&v)[32]) {
+__device__ __forceinline__ void plane_write(float *plane, int wbase, const cf (&v)[32]) {
     float *lo16 = plane + wbase;
     float *hi16 = lo16 + 16 * (32 * kRowPitch);
 #pragma unroll
@@ -138,7 +150,7 @@ __device__ __forceinline__ void plane_write(float *plane, int wbase, const f2 (&
     }
 }
 template<int COMP>
-__device__ __forceinline__ void plane_read(const float *plane, int row, f2 (&v)[32]) {
+__device__ __forceinline__ void plane_read(const float *plane, int row, cf (&v)[32]) {
     const f2 *r = (const f2 *) (plane + row * kRowPitch);
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
@@ -146,6 +158,15 @@ __device__ __forceinline__ void plane_read(const float *plane, int row, f2 (&v)[
         if (COMP == 0) { v[2 * m].x = t.x; v[2 * m + 1].x = t.y; }
         else           { v[2 * m].y = t.x; v[2 * m + 1].y = t.y; }
     }
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e.
+// every wave would wait at each of the ~12 barriers per row for its outstanding global
+// stores (and prefetched loads); nothing here communicates through global memory.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 __device__ __forceinline__ float bperm(int byte_addr, float x) {
@@ -192,6 +213,14 @@ __device__ __forceinline__ int per_row(int x) {
     asm volatile("" : "+v"(x));
     return x;
 }
+// Thread id rebuilt from the wave number (an SGPR) and the hardware lane count, so that not
+// even threadIdx.x itself has to stay in a VGPR across the row.
+__device__ __forceinline__ int thread_id(int wave_sgpr) {
+    int zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero));      // opaque 0: the two mbcnt below cannot be hoisted
+    const int lane = __builtin_amdgcn_mbcnt_hi(-1, __builtin_amdgcn_mbcnt_lo(-1, zero));
+    return (wave_sgpr << 6) | lane;
+}
 
 // Every workgroup alternates a memory phase (load a row / store a row) with ~12 us of
 // register/LDS work during which it issues no HBM traffic.  Workgroups launched together
@@ -220,67 +249,88 @@ __global__ __launch_bounds__(1024) void rfft64k_kernel(const float *__restrict__
     stagger_start(stagger_ticks);
     __syncthreads();
 
-    int it = 0;
-    for (int row = blockIdx.x; row < batch; row += gridDim.x, ++it) {
-        const int t = per_row(threadIdx.x);
-        STAMP(0);
-        const int lane = t & 63, wave = t >> 6;
-        const int hi = t >> 5, lo = t & 31;          // (j2, j3) in pass 1; (k1, j3) in pass 2
+    const int wave_sgpr = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-        // row descriptors: wave-uniform base, per-lane 32-bit byte offset, SGPR/immediate steps
-        const __amdgpu_buffer_rsrc_t rin =
-            __builtin_amdgcn_make_buffer_rsrc((void *) (x + (size_t) row * 65536), 0, 65536 * 4 * IO_ON, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rout =
-            __builtin_amdgcn_make_buffer_rsrc((void *) (X + (size_t) row * (kM + 1)), 0, (kM + 1) * 8 * IO_ON, 0x00020000);
-
-        f2 v[32];
+    // The row loop is software pipelined on the loads: row r+1's 32 loads per lane are issued
+    // in the tail of row r, as soon as the spectrum has left the registers for the LDS staging
+    // area and BEFORE row r's stores are issued, so that (vmcnt retires in order) pass 1 of
+    // the next row never waits behind the previous row's stores.
+    cf v[32];
+    {
+        const int row0 = blockIdx.x;
+        const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(
+            (void *) (x + (size_t) row0 * 65536), 0, row0 < batch ? 65536 * 4 * IO_ON : 0, 0x00020000);
+        const int load_off = thread_id(wave_sgpr) * 8;
 #pragma unroll
         for (int j1 = 0; j1 < 32; ++j1)
-            v[j1] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rin, t * 8, j1 * 8192, 0));
+            v[j1] = to_cf(__builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r0, load_off, j1 * 8192, 0)));
+    }
+
+    int it = 0;
+    for (int row = blockIdx.x; row < batch; row += gridDim.x, ++it) {
+        // thread-derived indices are re-derived per phase from a laundered thread id (see
+        // per_row): kept live across the row they cost ~10 VGPRs, which the compiler spills, and
+        // every scratch reload drains vmcnt, i.e. waits for all outstanding global stores.
+        STAMP(0);
+
+        // row descriptors: wave-uniform base, per-lane 32-bit byte offset, SGPR/immediate steps.
+        // The next row's descriptor has zero records past the end of the batch: loads return 0.
+        const int next_row = row + gridDim.x;
+        const __amdgpu_buffer_rsrc_t rnext = __builtin_amdgcn_make_buffer_rsrc(
+            (void *) (x + (size_t) next_row * 65536), 0, next_row < batch ? 65536 * 4 * IO_ON : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rout =
+            __builtin_amdgcn_make_buffer_rsrc((void *) (X + (size_t) row * (kM + 1)), 0, (kM + 1) * 8 * IO_ON, 0x00020000);
 
         STAMP(1);                                          // loads issued
         // ---- pass 1 (over j1) and twiddle W_1024^{j2 k1}
         if (!SKIP(1)) dft32<false>(v);
         if (!SKIP(2)) {
+            const int hi = thread_id(wave_sgpr) >> 5;      // j2
 #pragma unroll
-            for (int k1 = 1; k1 < 32; ++k1) v[br5(k1)] = cmul(v[br5(k1)], w1024[hi * k1]);
+            for (int k1 = 1; k1 < 32; ++k1) v[br5(k1)] = cmul(v[br5(k1)], to_cf(w1024[hi * k1]));
         }
 
         // ---- exchange 1: (j2, j3)[k1] -> (k1, j3)[j2];  row = k1*32 + j3 (slot k1), col = j2
-        const int wbase1 = lo * kRowPitch + hi;
-        f2 u[32];
+        const int t = thread_id(wave_sgpr);
+        const int wbase1 = (t & 31) * kRowPitch + (t >> 5);
+        cf u[32];
         STAMP(2);                                          // pass 1 done (includes the wait for the loads)
-        if (!SKIP(8)) __syncthreads();                     // plane free (previous row's readers done)
+        // Barriers sit AFTER each read phase (not before each write phase): a wave's LDS writes
+        // then overlap the tail of its own butterflies and the other waves' arithmetic.
         if (!SKIP(4)) plane_write<0>(plane, wbase1, v);
-        if (!SKIP(8)) __syncthreads();
+        if (!SKIP(8)) lds_barrier();
         if (!SKIP(4)) plane_read<0>(plane, t, u); else { for (int i = 0; i < 32; ++i) u[i] = v[31 - i]; }
-        if (!SKIP(8)) __syncthreads();
+        if (!SKIP(8)) lds_barrier();
         if (!SKIP(4)) plane_write<1>(plane, wbase1, v);
-        if (!SKIP(8)) __syncthreads();
+        if (!SKIP(8)) lds_barrier();
         if (!SKIP(4)) plane_read<1>(plane, t, u);
+        if (!SKIP(8)) lds_barrier();                     // plane free for exchange 2
         STAMP(3);                                          // exchange 1 done
 
         // ---- pass 2 (over j2) and twiddle W_32768^{j3 k1} * W_1024^{j3 k2}
         if (!SKIP(1)) dft32<false>(u);
         if (!SKIP(2)) {
-            const f2 tw2_base = aux[kAuxW32768 + hi * lo];             // W_32768^{j3 k1}
+            const int t2 = thread_id(wave_sgpr);
+            const int hi = t2 >> 5, lo = t2 & 31;                      // (k1, j3)
+            const cf tw2_base = to_cf(aux[kAuxW32768 + hi * lo]);             // W_32768^{j3 k1}
             u[0] = cmul(u[0], tw2_base);
 #pragma unroll
-            for (int k2 = 1; k2 < 32; ++k2) u[br5(k2)] = cmul(u[br5(k2)], cmul(tw2_base, w1024[lo * k2]));
+            for (int k2 = 1; k2 < 32; ++k2) u[br5(k2)] = cmul(u[br5(k2)], cmul(tw2_base, to_cf(w1024[lo * k2])));
         }
 
         // ---- exchange 2: (k1, j3)[k2] -> column k' = k1 + 32 k2, [j3];  row = k' (slot k2), col = j3
-        const int wbase2 = hi * kRowPitch + lo;
-        const int kp = column_of(wave, lane);
+        const int t3 = thread_id(wave_sgpr);
+        const int wbase2 = (t3 >> 5) * kRowPitch + (t3 & 31);
+        const int kp2 = column_of(t3 >> 6, t3 & 63);
         STAMP(4);                                          // pass 2 done
-        if (!SKIP(8)) __syncthreads();
         if (!SKIP(4)) plane_write<0>(plane, wbase2, u);
-        if (!SKIP(8)) __syncthreads();
-        if (!SKIP(4)) plane_read<0>(plane, kp, v); else { for (int i = 0; i < 32; ++i) v[i] = u[31 - i]; }
-        if (!SKIP(8)) __syncthreads();
+        if (!SKIP(8)) lds_barrier();
+        if (!SKIP(4)) plane_read<0>(plane, kp2, v); else { for (int i = 0; i < 32; ++i) v[i] = u[31 - i]; }
+        if (!SKIP(8)) lds_barrier();
         if (!SKIP(4)) plane_write<1>(plane, wbase2, u);
-        if (!SKIP(8)) __syncthreads();
-        if (!SKIP(4)) plane_read<1>(plane, kp, v);
+        if (!SKIP(8)) lds_barrier();
+        if (!SKIP(4)) plane_read<1>(plane, kp2, v);
+        if (!SKIP(8)) lds_barrier();                     // plane free for the next row's exchange 1
         STAMP(5);                                          // exchange 2 done
 
         // ---- pass 3 (over j3): v[p] = Z[k' + 1024 br5(p)]
@@ -288,49 +338,97 @@ __global__ __launch_bounds__(1024) void rfft64k_kernel(const float *__restrict__
         STAMP(6);                                          // pass 3 done
 
         // ---- packed-real post-pass.  Rows 0..15 of this column pair with rows 31..16 of the
-        // partner column (odd registers there); fetch them, finish both bins of each pair.
+        // partner column (odd registers there); fetch them, finish both bins of each pair:
+        // xk[k3] = X[k], xm[k3] = X[M-k], k = k' + 1024 k3.
+        const int t4 = thread_id(wave_sgpr);
+        const int lane = t4 & 63, wave = t4 >> 6;
+        const int kp = column_of(wave, lane);
         const int partner_addr = ((wave == 0 && (lane == 63 || lane == 0)) ? lane : 63 - lane) * 4;
-        if (wave == 0 && lane == 0) {                      // bin M/2 = conj Z[M/2] (dsc_fft.h:218)
-            const f2 mid = f2{v[br5(16)].x, -v[br5(16)].y};
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, mid), rout, (kM / 2) * 8, 0, 0);
+        cf xk[16], xm[16];
+#pragma unroll
+        for (int k3 = 0; k3 < 16; ++k3) {
+            const int src = 31 - br5(k3);                  // = br5(31 - k3)
+            xm[k3].x = bperm(partner_addr, v[src].x);
+            xm[k3].y = bperm(partner_addr, v[src].y);
         }
-        // -(i/2) W_65536^{k'}: the post-pass multiplies (a - conj b) by -i w / 2
-        const f2 wpost = aux[kAuxW65536 + kp];
-        const f2 post_base = f2{0.5f * wpost.y, -0.5f * wpost.x};
-        const int off_k = kp * 8;                               // X[k],   k = k' + 1024 k3: + k3 * 8192
-        const int off_mk = (kM - 15 * 1024 - kp) * 8;           // X[M-k]:                  + (15 - k3) * 8192
+        const cf zmid = v[br5(16)];                        // Z[M/2] in column 0
+        if (wave == 0) {                                   // column 0 pairs row k3 with row 32 - k3 of itself
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {                  // two batches of 8 pairs: VGPR budget
-            f2 b[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int k3 = half * 8 + i;
-                const int src = 31 - br5(k3);                  // = br5(31 - k3)
-                b[i].x = bperm(partner_addr, v[src].x);
-                b[i].y = bperm(partner_addr, v[src].y);
-            }
-            if (wave == 0) {                                   // column 0 pairs row k3 with row 32 - k3 of itself
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const f2 own = v[br5((32 - (half * 8 + i)) & 31)];
-                    b[i] = lane == 0 ? own : b[i];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int k3 = half * 8 + i;
-                const f2 a = v[br5(k3)];
-                const f2 s = f2{a.x + b[i].x, a.y - b[i].y};          // a + conj b
-                const f2 d = f2{a.x - b[i].x, a.y + b[i].y};          // a - conj b
-                const f2 c = f2{root64_re(k3), root64_im(k3)};        // W_64^{k3} = W_65536^{1024 k3}
-                const f2 w = (k3 == 0 || SKIP(16)) ? post_base : cmul(post_base, c);
-                const f2 wd = SKIP(16) ? d : cmul(d, w);
-                const f2 xk = f2{0.5f * s.x + wd.x, 0.5f * s.y + wd.y};
-                const f2 xm = f2{0.5f * s.x - wd.x, wd.y - 0.5f * s.y};
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, xk), rout, off_k, k3 * 8192, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, xm), rout, off_mk, (15 - k3) * 8192, 0);
+            for (int k3 = 0; k3 < 16; ++k3) {
+                const cf own = v[br5((32 - k3) & 31)];
+                xm[k3] = lane == 0 ? own : xm[k3];
             }
         }
+        {
+            // -(i/2) W_65536^{k'}: the post-pass multiplies (a - conj b) by -i w / 2
+            const cf wpost = to_cf(aux[kAuxW65536 + kp]);
+            const cf post_base = cf{0.5f * wpost.y, -0.5f * wpost.x};
+#pragma unroll
+            for (int k3 = 0; k3 < 16; ++k3) {
+                const cf a = v[br5(k3)], b = xm[k3];
+                const cf s = cf{a.x + b.x, a.y - b.y};                // a + conj b
+                const cf d = cf{a.x - b.x, a.y + b.y};                // a - conj b
+                const cf c = cf{root64_re(k3), root64_im(k3)};        // W_64^{k3} = W_65536^{1024 k3}
+                const cf w = (k3 == 0 || SKIP(16)) ? post_base : cmul(post_base, c);
+                const cf wd = SKIP(16) ? d : cmul(d, w);
+                xk[k3] = cf{0.5f * s.x + wd.x, 0.5f * s.y + wd.y};
+                xm[k3] = cf{0.5f * s.x - wd.x, wd.y - 0.5f * s.y};
+            }
+        }
+
+        // ---- store.  Output rows are 32769 bins long, so a row starts 8 * (row mod 16) bytes
+        // past a 128-B line; storing each lane's bins where the FFT left them would cut every
+        // 256-B piece across three lines (measured: ~20 % of the HBM rate lost to partial
+        // lines).  Instead the spectrum goes through the (now idle) LDS plane half a row at a
+        // time and is stored as whole, 128-B aligned lines, 16 B per lane.
+        f2 *stage = (f2 *) plane;
+        const int skew = (int) ((((size_t) (X + (size_t) row * (kM + 1))) >> 3) & 15);     // bins past a line start
+        // half 1: bins [0, 16384 - skew)
+#pragma unroll
+        for (int k3 = 0; k3 < 16; ++k3) stage[kp + 1024 * k3] = to_f2(xk[k3]);
+        const cf xk15 = xk[15];
+        const int load_off = thread_id(wave_sgpr) * 8;
+#pragma unroll
+        for (int j1 = 0; j1 < 16; ++j1)                    // xk[] is dead: first half of the next row
+            v[j1] = to_cf(__builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rnext, load_off, j1 * 8192, 0)));
+        if (!SKIP(8)) lds_barrier();
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int k = 2 * (t4 + 1024 * m) - skew;       // first bin of this lane's 16-B chunk
+            if (k >= 0) {
+                const f2 lo2 = stage[k], hi2 = stage[k + 1];
+                const f4 q = f4{lo2.x, lo2.y, hi2.x, hi2.y};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, q), rout, k * 8, 0, 0);
+            } else if (k == -1) {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, stage[0]), rout, 0, 0, 0);
+            }
+            if (m & 1) __builtin_amdgcn_sched_barrier(0);       // at most two chunks of staging reads in flight (VGPR budget)
+        }
+        if (!SKIP(8)) lds_barrier();
+        // half 2: bins [16384 - skew, 32768], staged at index bin - kStage2
+        constexpr int kStage2 = kM / 2 - 16;
+#pragma unroll
+        for (int k3 = 0; k3 < 16; ++k3) stage[(kM - kStage2) - kp - 1024 * k3] = to_f2(xm[k3]);
+        if (kp >= 1009) stage[kp + 15 * 1024 - kStage2] = to_f2(xk15);               // bins 16369..16383
+        if (t4 == 0) stage[kM / 2 - kStage2] = f2{zmid.x, -zmid.y};            // bin M/2 = conj Z[M/2] (dsc_fft.h:218)
+#pragma unroll
+        for (int j1 = 16; j1 < 32; ++j1)                   // xm[] is dead: second half of the next row
+            v[j1] = to_cf(__builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rnext, load_off, j1 * 8192, 0)));
+        if (!SKIP(8)) lds_barrier();
+#pragma unroll
+        for (int m = 0; m < 9; ++m) {
+            if (m == 8 && wave != 0) break;                // bins past 32768 + 15 do not exist
+            const int k = kM / 2 + 2 * (t4 + 1024 * m) - skew;
+            if (k + 1 <= kM) {
+                const f2 lo2 = stage[k - kStage2], hi2 = stage[k + 1 - kStage2];
+                const f4 q = f4{lo2.x, lo2.y, hi2.x, hi2.y};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, q), rout, k * 8, 0, 0);
+            } else if (k == kM) {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, stage[k - kStage2]), rout, k * 8, 0, 0);
+            }
+            if (m & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!SKIP(8)) lds_barrier();                     // plane free for the next row's exchange 1
         STAMP(7);                                          // post-pass done, stores issued
     }
 }

@@ -72,5 +72,10 @@ int main() {
     rep("rowcopy L16 S16 512thr x2/CU pitch 262144", timeit([&] { hipLaunchKernelGGL((rowcopy<16, 16, 512>), dim3(512), dim3(512), 0, 0, x, y, batch, 262144); }), rb);
     rep("rowcopy L16 S16 256thr x4/CU pitch 262144", timeit([&] { hipLaunchKernelGGL((rowcopy<16, 16, 256>), dim3(1024), dim3(256), 0, 0, x, y, batch, 262144); }), rb);
     rep("rowcopy L8 S8 1024thr grid 512 (2 WG/CU if they fit)", timeit([&] { hipLaunchKernelGGL((rowcopy<8, 8, 1024>), dim3(512), dim3(1024), 0, 0, x, y, batch, 262152); }), rb);
+    for (int g : {8, 32, 64, 128, 256}) {
+        char name[128]; snprintf(name, sizeof name, "rowcopy L8 S16 1024thr aligned, grid %d (per-CU rate = total/grid)", g);
+        float ms = timeit([&] { hipLaunchKernelGGL((rowcopy<8, 16, 1024>), dim3(g), dim3(1024), 0, 0, x, y, batch / 4, 262144); });
+        printf("%-58s %.3f ms  %.0f GB/s total, %.1f GB/s per CU, %.2f us per row\n", name, ms, rb / 4 / ms / 1e6, rb / 4 / ms / 1e6 / g, ms * 1e3 / (batch / 4 / g));
+    }
     return 0;
 }

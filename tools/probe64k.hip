@@ -1,6 +1,6 @@
 // tools/probe64k.hip — diagnostic build of the register-resident rfft kernel with per-phase
 // realtime stamps (wave 0 of every workgroup).  Not part of the product or of the tests.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -Iinclude tools/probe64k.hip -o tools/probe64k
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -fno-slp-vectorize -Iinclude tools/probe64k.hip -o tools/probe64k
 //   tools/probe64k [batch] [stagger_ticks]
 #define DSC_R2C64K_PROBE 1
 // -DDSC_R2C64K_STAMPS adds per-phase stamps; -DDSC_R2C64K_SKIP=<bits> removes parts (ablation)
