@@ -222,22 +222,10 @@ __device__ __forceinline__ int thread_id(int wave_sgpr) {
     return (wave_sgpr << 6) | lane;
 }
 
-// Every workgroup alternates a memory phase (load a row / store a row) with ~12 us of
-// register/LDS work during which it issues no HBM traffic.  Workgroups launched together
-// stay in lockstep, so the whole chip alternates between "all loading" and "all computing".
-// Delaying every other workgroup of each XCD by half a period interleaves the two phases:
-// while one half computes, the other half has the HBM to itself.  (100 MHz realtime ticks.)
-__device__ __forceinline__ void stagger_start(int ticks) {
-    if (ticks > 0 && ((blockIdx.x >> 3) & 1)) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while ((long long) (__builtin_amdgcn_s_memrealtime() - t0) < ticks) __builtin_amdgcn_s_sleep(16);
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // forward: x [batch][65536] f32  ->  X [batch][32769] c32
 __global__ __launch_bounds__(1024) void rfft64k_kernel(const float *__restrict__ x, f2 *__restrict__ X, int batch,
-                                                       const f2 *__restrict__ aux, int stagger_ticks PROBE_ARGS) {
+                                                       const f2 *__restrict__ aux PROBE_ARGS) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *plane = lds;
     f2 *w1024 = (f2 *) (lds + kPlaneFloats);
@@ -246,7 +234,6 @@ __global__ __launch_bounds__(1024) void rfft64k_kernel(const float *__restrict__
         const int t0 = threadIdx.x;
         w1024[t0] = aux[kAuxW1024 + t0];
     }
-    stagger_start(stagger_ticks);
     __syncthreads();
 
     const int wave_sgpr = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -395,11 +382,11 @@ __global__ __launch_bounds__(1024) void rfft64k_kernel(const float *__restrict__
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             const int k = 2 * (t4 + 1024 * m) - skew;       // first bin of this lane's 16-B chunk
-            if (k >= 0) {
+            if (m > 0 || k >= 0) {                          // only the row's first chunk can start before bin 0
                 const f2 lo2 = stage[k], hi2 = stage[k + 1];
                 const f4 q = f4{lo2.x, lo2.y, hi2.x, hi2.y};
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, q), rout, k * 8, 0, 0);
-            } else if (k == -1) {
+            } else if (m == 0 && k == -1) {
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, stage[0]), rout, 0, 0, 0);
             }
             if (m & 1) __builtin_amdgcn_sched_barrier(0);       // at most two chunks of staging reads in flight (VGPR budget)
@@ -419,17 +406,162 @@ __global__ __launch_bounds__(1024) void rfft64k_kernel(const float *__restrict__
         for (int m = 0; m < 9; ++m) {
             if (m == 8 && wave != 0) break;                // bins past 32768 + 15 do not exist
             const int k = kM / 2 + 2 * (t4 + 1024 * m) - skew;
-            if (k + 1 <= kM) {
+            if (m < 8 || k + 1 <= kM) {                     // only the row's last chunks can run past bin M
                 const f2 lo2 = stage[k - kStage2], hi2 = stage[k + 1 - kStage2];
                 const f4 q = f4{lo2.x, lo2.y, hi2.x, hi2.y};
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, q), rout, k * 8, 0, 0);
-            } else if (k == kM) {
+            } else if (m == 8 && k == kM) {
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, stage[k - kStage2]), rout, k * 8, 0, 0);
             }
             if (m & 1) __builtin_amdgcn_sched_barrier(0);
         }
         if (!SKIP(8)) lds_barrier();                     // plane free for the next row's exchange 1
         STAMP(7);                                          // post-pass done, stores issued
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// inverse: X [batch][32769] c32  ->  x [batch][65536] f32        (dsc_irfft, dsc_fft.h:194-236)
+//
+// The forward pipeline run backwards.  The bins are read in the column layout of the forward
+// post-pass (lane l and lane 63-l of a wave hold columns c and 1024-c, 32 rows k = c + 1024 a
+// each), the packed-real pre-pass Z[k] = h1 + conj(w) h2 pairs them through ds_bpermute, and
+// three conjugate-twiddle passes over (a, b, c') with k = 1024 a + 32 b + c' end with thread t
+// holding z[t + 1024 r]: the time samples leave as aligned, coalesced 8-B stores.
+// The 2/(2n) scale of the reference (dsc_fft.h:232) is folded into the pre-pass constants.
+__global__ __launch_bounds__(1024) void irfft64k_kernel(const f2 *__restrict__ X, float *__restrict__ x, int batch,
+                                                        const f2 *__restrict__ aux) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *plane = lds;
+    f2 *w1024 = (f2 *) (lds + kPlaneFloats);
+    w1024[threadIdx.x] = aux[kAuxW1024 + threadIdx.x];
+    __syncthreads();
+
+    const int wave_sgpr = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr float kScale = 1.0f / (float) kM;
+
+    for (int row = blockIdx.x; row < batch; row += gridDim.x) {
+        const __amdgpu_buffer_rsrc_t rin =
+            __builtin_amdgcn_make_buffer_rsrc((void *) (X + (size_t) row * (kM + 1)), 0, (kM + 1) * 8, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rout =
+            __builtin_amdgcn_make_buffer_rsrc((void *) (x + (size_t) row * 65536), 0, 65536 * 4, 0x00020000);
+
+        // ---- load column c, rows a = 0..31: Y[c + 1024 a]
+        cf v[32];
+        cf y_last = cf{0.f, 0.f};
+        {
+            const int t0 = thread_id(wave_sgpr);
+            const int c = column_of(t0 >> 6, t0 & 63);
+#pragma unroll
+            for (int a = 0; a < 32; ++a)
+                v[a] = to_cf(__builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rin, c * 8, a * 8192, 0)));
+            if (c == 0) y_last = to_cf(__builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rin, kM * 8, 0, 0)));   // bin M
+        }
+
+        // ---- packed-real pre-pass (dsc_fft.h:199-228): rows 0..15 pair with rows 31..16 of the
+        // partner column.  Z[k] = s/2 + wq d,  Z[M-k] = conj(s/2 - wq d),  s = p + conj q,
+        // d = p - conj q,  wq = (i/2) conj(W_65536^k); everything pre-multiplied by 1/M.
+        {
+            const int t1 = thread_id(wave_sgpr);
+            const int lane = t1 & 63, wave = t1 >> 6;
+            const int c = column_of(wave, lane);
+            const int partner_addr = ((wave == 0 && (lane == 63 || lane == 0)) ? lane : 63 - lane) * 4;
+            // Column 0 (lane 0 of wave 0) pairs row a with row 32 - a of itself and row 0 with bin M.
+            // Shifting its rows 17..31 down by one (and putting bin M in row 31) turns that into
+            // the general "row a with row 31 - a of the partner" with itself as partner.
+            const cf y_mid = v[16];                        // bin M/2 pairs with itself
+            if (wave == 0) {
+#pragma unroll
+                for (int r = 16; r < 31; ++r) v[r] = lane == 0 ? v[r + 1] : v[r];
+                v[31] = lane == 0 ? y_last : v[31];
+                if (lane == 0) { v[0].y = 0.f; v[31].y = 0.f; }         // dsc_fft.h:227-228 reads the real parts only
+            }
+            const cf wpre = to_cf(aux[kAuxW65536 + c]);
+            const cf wq_base = cf{0.5f * kScale * wpre.y, 0.5f * kScale * wpre.x};      // (i/2) conj(W^c) / M
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {         // two batches of 8 pairs: VGPR budget
+                cf q[8], zm[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int a = half * 8 + i;
+                    q[i].x = bperm(partner_addr, v[31 - a].x);
+                    q[i].y = bperm(partner_addr, v[31 - a].y);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int a = half * 8 + i;
+                    const cf p = v[a];
+                    const cf s = cf{p.x + q[i].x, p.y - q[i].y};
+                    const cf d = cf{p.x - q[i].x, p.y + q[i].y};
+                    const cf cj = cf{root64_re(a), -root64_im(a)};       // conj(W_64^a)
+                    const cf wq = a == 0 ? wq_base : cmul(wq_base, cj);
+                    const cf wd = cmul(d, wq);
+                    v[a] = cf{0.5f * kScale * s.x + wd.x, 0.5f * kScale * s.y + wd.y};
+                    zm[i] = cf{0.5f * kScale * s.x - wd.x, wd.y - 0.5f * kScale * s.y};
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {              // the partner finished my rows 31..16
+                    const int a = half * 8 + i;
+                    v[31 - a].x = bperm(partner_addr, zm[i].x);
+                    v[31 - a].y = bperm(partner_addr, zm[i].y);
+                }
+            }
+            if (wave == 0) {                               // undo the shift of column 0
+#pragma unroll
+                for (int r = 31; r > 16; --r) v[r] = lane == 0 ? v[r - 1] : v[r];
+                v[16] = lane == 0 ? cf{kScale * y_mid.x, -kScale * y_mid.y} : v[16];   // Z[M/2] = conj Y[M/2] (dsc_fft.h:218)
+            }
+        }
+
+        // ---- pass 1 (over a), twiddle conj(W_1024^{b r1}), exchange 1: (b, c')[r1] -> (r1, c')[b]
+        dft32<true>(v);
+        cf u[32];
+        {
+            const int t2 = thread_id(wave_sgpr);
+            const int c = column_of(t2 >> 6, t2 & 63);
+            const int b = c >> 5;
+#pragma unroll
+            for (int r1 = 1; r1 < 32; ++r1) v[br5(r1)] = cmul_conj(v[br5(r1)], to_cf(w1024[b * r1]));
+            const int wbase1 = (c & 31) * kRowPitch + b;
+            plane_write<0>(plane, wbase1, v);
+            lds_barrier();
+            plane_read<0>(plane, t2, u);
+            lds_barrier();
+            plane_write<1>(plane, wbase1, v);
+            lds_barrier();
+            plane_read<1>(plane, t2, u);
+            lds_barrier();
+        }
+
+        // ---- pass 2 (over b), twiddle conj(W_32768^{c' r1} W_1024^{c' r2}), exchange 2 -> thread t, [c']
+        dft32<true>(u);
+        {
+            const int t3 = thread_id(wave_sgpr);
+            const int hi = t3 >> 5, lo = t3 & 31;          // (r1, c')
+            const cf tw2_base = to_cf(aux[kAuxW32768 + hi * lo]);
+            u[0] = cmul_conj(u[0], tw2_base);
+#pragma unroll
+            for (int r2 = 1; r2 < 32; ++r2) u[br5(r2)] = cmul_conj(u[br5(r2)], cmul(tw2_base, to_cf(w1024[lo * r2])));
+            const int wbase2 = hi * kRowPitch + lo;
+            plane_write<0>(plane, wbase2, u);
+            lds_barrier();
+            plane_read<0>(plane, t3, v);
+            lds_barrier();
+            plane_write<1>(plane, wbase2, u);
+            lds_barrier();
+            plane_read<1>(plane, t3, v);
+            lds_barrier();
+        }
+
+        // ---- pass 3 (over c'): v[p] = z[t + 1024 br5(p)] = (x[2j], x[2j+1])
+        dft32<true>(v);
+        {
+            const int t4 = thread_id(wave_sgpr);
+#pragma unroll
+            for (int p = 0; p < 32; ++p)
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, to_f2(v[p])), rout, t4 * 8, br5(p) * 8192, 0);
+        }
     }
 }
 
@@ -464,14 +596,17 @@ void dsc_launch_rfft64k(const float *x, void *X, int batch, const void *aux, int
         attr_set = true;
     }
     const int grid = batch < n_cu ? batch : n_cu;
-    static int stagger = -1;
-    if (stagger < 0) {
-        const char *e = getenv("DSC_STAGGER_TICKS");
-        stagger = e ? atoi(e) : 0;
-    }
-    hipLaunchKernelGGL(rfft64k_kernel, dim3(grid), dim3(1024), kLdsBytes, stream, x, (f2 *) X, batch, (const f2 *) aux,
-                       batch >= 2 * n_cu ? stagger : 0 PROBE_NULL);
+    hipLaunchKernelGGL(rfft64k_kernel, dim3(grid), dim3(1024), kLdsBytes, stream, x, (f2 *) X, batch, (const f2 *) aux PROBE_NULL);
 }
 
-void dsc_launch_irfft64k(const void *, float *, int, const void *, int, hipStream_t) {}
+void dsc_launch_irfft64k(const void *X, float *x, int batch, const void *aux, int n_cu, hipStream_t stream) {
+    if (batch <= 0) return;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void) hipFuncSetAttribute((const void *) irfft64k_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        attr_set = true;
+    }
+    const int grid = batch < n_cu ? batch : n_cu;
+    hipLaunchKernelGGL(irfft64k_kernel, dim3(grid), dim3(1024), kLdsBytes, stream, (const f2 *) X, x, batch, (const f2 *) aux);
+}
 void dsc_launch_filter64k(const float *, const void *, float *, int, const void *, int, hipStream_t) {}

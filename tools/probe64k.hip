@@ -35,7 +35,7 @@ int main(int argc, char **argv) {
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipMemset(stamps, 0, (size_t) grid * 64 * 16 * 8));
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(rfft64k_kernel, dim3(grid), dim3(1024), kLdsBytes, 0, x, X, batch, aux, stagger, use_stamps ? stamps : nullptr, io_on);
+        hipLaunchKernelGGL(rfft64k_kernel, dim3(grid), dim3(1024), kLdsBytes, 0, x, X, batch, aux, use_stamps ? stamps : nullptr, io_on);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("rep %d: %.3f ms\n", rep, ms);
