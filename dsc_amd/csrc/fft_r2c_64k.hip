@@ -179,47 +179,113 @@ __device__ __forceinline__ int column_of(int wave, int lane) {
     return kp == 1024 ? 512 : kp;
 }
 
-// Diagnostic build only (tools/probe64k.hip defines DSC_R2C64K_STAMPS): wave 0 of every
-// workgroup records 100 MHz realtime stamps per phase into a side buffer.
-#ifdef DSC_R2C64K_STAMPS
-#define STAMP(i)                                                                              \
-    do {                                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                    \
-        if (stamps && threadIdx.x == 0 && it < 64)                                            \
-            stamps[((size_t) blockIdx.x * 64 + it) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
-        __builtin_amdgcn_sched_barrier(0);                                                    \
-    } while (0)
-#else
-#define STAMP(i)
-#endif
-#ifdef DSC_R2C64K_PROBE            // extra kernel arguments of the diagnostic builds
-#define PROBE_ARGS , unsigned long long *stamps, int io_on
-#define PROBE_NULL , nullptr, 1
-#define IO_ON io_on                // 0: zero-record descriptors, every global access is dropped
+// Diagnostic builds (tools/probe64k.hip) add an `io_on` argument: 0 gives every buffer
+// descriptor zero records, i.e. all global accesses are dropped while the instruction stream
+// stays the same (compute-only timing).
+#ifdef DSC_R2C64K_PROBE
+#define PROBE_ARGS , int io_on
+#define PROBE_NULL , 1
+#define IO_ON io_on
 #else
 #define PROBE_ARGS
 #define PROBE_NULL
 #define IO_ON 1
 #endif
-#ifndef DSC_R2C64K_SKIP
-#define DSC_R2C64K_SKIP 0
-#endif
-#define SKIP(bit) ((DSC_R2C64K_SKIP) & (bit))   // compile-time ablation: 1 dft32, 2 twiddles, 4 LDS traffic, 8 barriers, 16 post-pass
 
 // Values derived from threadIdx are loop invariant; hipcc hoists every address built from
-// them out of the persistent row loop (dozens of VGPRs) and then spills them.  Passing the
-// thread id through an empty asm once per row keeps those computations inside the loop.
-__device__ __forceinline__ int per_row(int x) {
-    asm volatile("" : "+v"(x));
-    return x;
-}
-// Thread id rebuilt from the wave number (an SGPR) and the hardware lane count, so that not
-// even threadIdx.x itself has to stay in a VGPR across the row.
+// them out of the persistent row loop (dozens of VGPRs) and then spills them, and every
+// scratch reload drains vmcnt, i.e. waits for all outstanding global stores.  The thread id
+// is therefore rebuilt where it is needed from the wave number (an SGPR) and the hardware
+// lane count, behind an opaque zero that keeps the two mbcnt from being hoisted.
 __device__ __forceinline__ int thread_id(int wave_sgpr) {
     int zero;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(zero));      // opaque 0: the two mbcnt below cannot be hoisted
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
     const int lane = __builtin_amdgcn_mbcnt_hi(-1, __builtin_amdgcn_mbcnt_lo(-1, zero));
     return (wave_sgpr << 6) | lane;
+}
+
+__device__ __forceinline__ cf load_c(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return to_cf(__builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0)));
+}
+__device__ __forceinline__ void store_c(cf a, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, to_f2(a)), r, voff, soff, 0);
+}
+
+// One LDS transpose = re plane, then im plane.  Barriers sit AFTER each read phase (not before
+// each write phase): a wave's LDS writes then overlap the tail of its own butterflies and
+// the other waves' arithmetic; the last one leaves the plane free for whoever writes next.
+__device__ __forceinline__ void exchange(float *plane, int wbase, int row, const cf (&src)[32], cf (&dst)[32]) {
+    plane_write<0>(plane, wbase, src);
+    lds_barrier();
+    plane_read<0>(plane, row, dst);
+    lds_barrier();
+    plane_write<1>(plane, wbase, src);
+    lds_barrier();
+    plane_read<1>(plane, row, dst);
+    lds_barrier();
+}
+
+// Three passes of the 32768-point complex DFT (forward, or INV = conjugate twiddles).
+//   in : v[i] = element 1024 i + t of the input sequence, t = thread id, i = 0..31
+//        (forward: time samples z[j]; inverse: bins Z[k] — any thread may hold any column
+//         `col`, the exchange routes by column: pass `col` = the column this thread holds)
+//   out: v[p] = element col_out + 1024 br5(p) of the output sequence, where the caller picks
+//        which output column `col_out` this thread receives.
+template<bool INV>
+__device__ __forceinline__ void three_passes(cf (&v)[32], float *plane, const f2 *w1024, const f2 *aux, int wave_sgpr,
+                                             bool mirrored_in, bool mirrored_out) {
+    // ---- pass 1 (over the slow index) and twiddle W_1024^{hi r1}, hi = col >> 5
+    dft32<INV>(v);
+    cf u[32];
+    {
+        const int t = thread_id(wave_sgpr);
+        const int col = mirrored_in ? column_of(t >> 6, t & 63) : t;
+        const int hi = col >> 5;
+#pragma unroll
+        for (int r1 = 1; r1 < 32; ++r1) {
+            const cf w = to_cf(w1024[hi * r1]);
+            v[br5(r1)] = INV ? cmul_conj(v[br5(r1)], w) : cmul(v[br5(r1)], w);
+        }
+        // exchange 1: (hi, lo)[r1] -> thread (r1, lo), registers [hi];  LDS row = r1*32 + lo, col = hi
+        exchange(plane, (col & 31) * kRowPitch + hi, t, v, u);
+    }
+    // ---- pass 2 (over the middle index) and twiddle W_32768^{lo r1} W_1024^{lo r2}
+    dft32<INV>(u);
+    {
+        const int t = thread_id(wave_sgpr);
+        const int hi = t >> 5, lo = t & 31;              // (r1, lo)
+        const cf tw2_base = to_cf(aux[kAuxW32768 + hi * lo]);
+        u[0] = INV ? cmul_conj(u[0], tw2_base) : cmul(u[0], tw2_base);
+#pragma unroll
+        for (int r2 = 1; r2 < 32; ++r2) {
+            const cf w = cmul(tw2_base, to_cf(w1024[lo * r2]));
+            u[br5(r2)] = INV ? cmul_conj(u[br5(r2)], w) : cmul(u[br5(r2)], w);
+        }
+        // exchange 2: (r1, lo)[r2] -> output column r1 + 32 r2, registers [lo];  LDS row = column
+        const int col_out = mirrored_out ? column_of(t >> 6, t & 63) : t;
+        exchange(plane, hi * kRowPitch + lo, col_out, u, v);
+    }
+    // ---- pass 3 (over the fast index)
+    dft32<INV>(v);
+}
+
+// Packed-real relations on one pair of bins (dsc_fft.h:199-228), p = in[k], q = in[M-k]:
+//   s = p + conj q,  d = p - conj q,  out[k] = hs s + wq d,  out[M-k] = conj(hs s - wq d)
+// forward: hs = 1/2, wq = -(i/2) W^k;  inverse: hs = 1/(2M), wq = (i/2M) conj(W^k).
+__device__ __forceinline__ void real_pair(cf p, cf q, cf wq, float hs, cf &out_k, cf &out_mk) {
+    const cf s = cf{p.x + q.x, p.y - q.y};
+    const cf d = cf{p.x - q.x, p.y + q.y};
+    const cf wd = cmul(d, wq);
+    out_k = cf{hs * s.x + wd.x, hs * s.y + wd.y};
+    out_mk = cf{hs * s.x - wd.x, wd.y - hs * s.y};
+}
+
+// Lane layout of the spectrum side (forward post-pass / inverse pre-pass): lane l and lane
+// 63-l of a wave hold columns c and 1024-c; rows a of c pair with rows 31-a of 1024-c.
+// Column 0 (wave 0, lane 0) pairs with itself shifted by one row, column 512 (wave 0, lane 63)
+// with itself; both use themselves as ds_bpermute partner.
+__device__ __forceinline__ int partner_byte_addr(int wave, int lane) {
+    return ((wave == 0 && (lane == 63 || lane == 0)) ? lane : 63 - lane) * 4;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -229,11 +295,7 @@ __global__ __launch_bounds__(1024) void rfft64k_kernel(const float *__restrict__
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *plane = lds;
     f2 *w1024 = (f2 *) (lds + kPlaneFloats);
-
-    {
-        const int t0 = threadIdx.x;
-        w1024[t0] = aux[kAuxW1024 + t0];
-    }
+    w1024[threadIdx.x] = aux[kAuxW1024 + threadIdx.x];
     __syncthreads();
 
     const int wave_sgpr = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -249,17 +311,10 @@ __global__ __launch_bounds__(1024) void rfft64k_kernel(const float *__restrict__
             (void *) (x + (size_t) row0 * 65536), 0, row0 < batch ? 65536 * 4 * IO_ON : 0, 0x00020000);
         const int load_off = thread_id(wave_sgpr) * 8;
 #pragma unroll
-        for (int j1 = 0; j1 < 32; ++j1)
-            v[j1] = to_cf(__builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r0, load_off, j1 * 8192, 0)));
+        for (int j1 = 0; j1 < 32; ++j1) v[j1] = load_c(r0, load_off, j1 * 8192);
     }
 
-    int it = 0;
-    for (int row = blockIdx.x; row < batch; row += gridDim.x, ++it) {
-        // thread-derived indices are re-derived per phase from a laundered thread id (see
-        // per_row): kept live across the row they cost ~10 VGPRs, which the compiler spills, and
-        // every scratch reload drains vmcnt, i.e. waits for all outstanding global stores.
-        STAMP(0);
-
+    for (int row = blockIdx.x; row < batch; row += gridDim.x) {
         // row descriptors: wave-uniform base, per-lane 32-bit byte offset, SGPR/immediate steps.
         // The next row's descriptor has zero records past the end of the batch: loads return 0.
         const int next_row = row + gridDim.x;
@@ -268,61 +323,7 @@ __global__ __launch_bounds__(1024) void rfft64k_kernel(const float *__restrict__
         const __amdgpu_buffer_rsrc_t rout =
             __builtin_amdgcn_make_buffer_rsrc((void *) (X + (size_t) row * (kM + 1)), 0, (kM + 1) * 8 * IO_ON, 0x00020000);
 
-        STAMP(1);                                          // loads issued
-        // ---- pass 1 (over j1) and twiddle W_1024^{j2 k1}
-        if (!SKIP(1)) dft32<false>(v);
-        if (!SKIP(2)) {
-            const int hi = thread_id(wave_sgpr) >> 5;      // j2
-#pragma unroll
-            for (int k1 = 1; k1 < 32; ++k1) v[br5(k1)] = cmul(v[br5(k1)], to_cf(w1024[hi * k1]));
-        }
-
-        // ---- exchange 1: (j2, j3)[k1] -> (k1, j3)[j2];  row = k1*32 + j3 (slot k1), col = j2
-        const int t = thread_id(wave_sgpr);
-        const int wbase1 = (t & 31) * kRowPitch + (t >> 5);
-        cf u[32];
-        STAMP(2);                                          // pass 1 done (includes the wait for the loads)
-        // Barriers sit AFTER each read phase (not before each write phase): a wave's LDS writes
-        // then overlap the tail of its own butterflies and the other waves' arithmetic.
-        if (!SKIP(4)) plane_write<0>(plane, wbase1, v);
-        if (!SKIP(8)) lds_barrier();
-        if (!SKIP(4)) plane_read<0>(plane, t, u); else { for (int i = 0; i < 32; ++i) u[i] = v[31 - i]; }
-        if (!SKIP(8)) lds_barrier();
-        if (!SKIP(4)) plane_write<1>(plane, wbase1, v);
-        if (!SKIP(8)) lds_barrier();
-        if (!SKIP(4)) plane_read<1>(plane, t, u);
-        if (!SKIP(8)) lds_barrier();                     // plane free for exchange 2
-        STAMP(3);                                          // exchange 1 done
-
-        // ---- pass 2 (over j2) and twiddle W_32768^{j3 k1} * W_1024^{j3 k2}
-        if (!SKIP(1)) dft32<false>(u);
-        if (!SKIP(2)) {
-            const int t2 = thread_id(wave_sgpr);
-            const int hi = t2 >> 5, lo = t2 & 31;                      // (k1, j3)
-            const cf tw2_base = to_cf(aux[kAuxW32768 + hi * lo]);             // W_32768^{j3 k1}
-            u[0] = cmul(u[0], tw2_base);
-#pragma unroll
-            for (int k2 = 1; k2 < 32; ++k2) u[br5(k2)] = cmul(u[br5(k2)], cmul(tw2_base, to_cf(w1024[lo * k2])));
-        }
-
-        // ---- exchange 2: (k1, j3)[k2] -> column k' = k1 + 32 k2, [j3];  row = k' (slot k2), col = j3
-        const int t3 = thread_id(wave_sgpr);
-        const int wbase2 = (t3 >> 5) * kRowPitch + (t3 & 31);
-        const int kp2 = column_of(t3 >> 6, t3 & 63);
-        STAMP(4);                                          // pass 2 done
-        if (!SKIP(4)) plane_write<0>(plane, wbase2, u);
-        if (!SKIP(8)) lds_barrier();
-        if (!SKIP(4)) plane_read<0>(plane, kp2, v); else { for (int i = 0; i < 32; ++i) v[i] = u[31 - i]; }
-        if (!SKIP(8)) lds_barrier();
-        if (!SKIP(4)) plane_write<1>(plane, wbase2, u);
-        if (!SKIP(8)) lds_barrier();
-        if (!SKIP(4)) plane_read<1>(plane, kp2, v);
-        if (!SKIP(8)) lds_barrier();                     // plane free for the next row's exchange 1
-        STAMP(5);                                          // exchange 2 done
-
-        // ---- pass 3 (over j3): v[p] = Z[k' + 1024 br5(p)]
-        if (!SKIP(1)) dft32<false>(v);
-        STAMP(6);                                          // pass 3 done
+        three_passes<false>(v, plane, w1024, aux, wave_sgpr, false, true);     // v[p] = Z[k' + 1024 br5(p)]
 
         // ---- packed-real post-pass.  Rows 0..15 of this column pair with rows 31..16 of the
         // partner column (odd registers there); fetch them, finish both bins of each pair:
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(1024) void rfft64k_kernel(const float *__restrict__
         const int t4 = thread_id(wave_sgpr);
         const int lane = t4 & 63, wave = t4 >> 6;
         const int kp = column_of(wave, lane);
-        const int partner_addr = ((wave == 0 && (lane == 63 || lane == 0)) ? lane : 63 - lane) * 4;
+        const int partner_addr = partner_byte_addr(wave, lane);
         cf xk[16], xm[16];
 #pragma unroll
         for (int k3 = 0; k3 < 16; ++k3) {
@@ -347,19 +348,13 @@ __global__ __launch_bounds__(1024) void rfft64k_kernel(const float *__restrict__
             }
         }
         {
-            // -(i/2) W_65536^{k'}: the post-pass multiplies (a - conj b) by -i w / 2
             const cf wpost = to_cf(aux[kAuxW65536 + kp]);
-            const cf post_base = cf{0.5f * wpost.y, -0.5f * wpost.x};
+            const cf post_base = cf{0.5f * wpost.y, -0.5f * wpost.x};          // -(i/2) W_65536^{k'}
 #pragma unroll
             for (int k3 = 0; k3 < 16; ++k3) {
-                const cf a = v[br5(k3)], b = xm[k3];
-                const cf s = cf{a.x + b.x, a.y - b.y};                // a + conj b
-                const cf d = cf{a.x - b.x, a.y + b.y};                // a - conj b
-                const cf c = cf{root64_re(k3), root64_im(k3)};        // W_64^{k3} = W_65536^{1024 k3}
-                const cf w = (k3 == 0 || SKIP(16)) ? post_base : cmul(post_base, c);
-                const cf wd = SKIP(16) ? d : cmul(d, w);
-                xk[k3] = cf{0.5f * s.x + wd.x, 0.5f * s.y + wd.y};
-                xm[k3] = cf{0.5f * s.x - wd.x, wd.y - 0.5f * s.y};
+                const cf c = cf{root64_re(k3), root64_im(k3)};                 // W_64^{k3} = W_65536^{1024 k3}
+                const cf w = k3 == 0 ? post_base : cmul(post_base, c);
+                real_pair(v[br5(k3)], xm[k3], w, 0.5f, xk[k3], xm[k3]);
             }
         }
 
@@ -376,9 +371,8 @@ __global__ __launch_bounds__(1024) void rfft64k_kernel(const float *__restrict__
         const cf xk15 = xk[15];
         const int load_off = thread_id(wave_sgpr) * 8;
 #pragma unroll
-        for (int j1 = 0; j1 < 16; ++j1)                    // xk[] is dead: first half of the next row
-            v[j1] = to_cf(__builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rnext, load_off, j1 * 8192, 0)));
-        if (!SKIP(8)) lds_barrier();
+        for (int j1 = 0; j1 < 16; ++j1) v[j1] = load_c(rnext, load_off, j1 * 8192);      // xk[] is dead: next row, first half
+        lds_barrier();
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             const int k = 2 * (t4 + 1024 * m) - skew;       // first bin of this lane's 16-B chunk
@@ -391,17 +385,16 @@ __global__ __launch_bounds__(1024) void rfft64k_kernel(const float *__restrict__
             }
             if (m & 1) __builtin_amdgcn_sched_barrier(0);       // at most two chunks of staging reads in flight (VGPR budget)
         }
-        if (!SKIP(8)) lds_barrier();
+        lds_barrier();
         // half 2: bins [16384 - skew, 32768], staged at index bin - kStage2
         constexpr int kStage2 = kM / 2 - 16;
 #pragma unroll
         for (int k3 = 0; k3 < 16; ++k3) stage[(kM - kStage2) - kp - 1024 * k3] = to_f2(xm[k3]);
-        if (kp >= 1009) stage[kp + 15 * 1024 - kStage2] = to_f2(xk15);               // bins 16369..16383
+        if (kp >= 1009) stage[kp + 15 * 1024 - kStage2] = to_f2(xk15);         // bins 16369..16383
         if (t4 == 0) stage[kM / 2 - kStage2] = f2{zmid.x, -zmid.y};            // bin M/2 = conj Z[M/2] (dsc_fft.h:218)
 #pragma unroll
-        for (int j1 = 16; j1 < 32; ++j1)                   // xm[] is dead: second half of the next row
-            v[j1] = to_cf(__builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rnext, load_off, j1 * 8192, 0)));
-        if (!SKIP(8)) lds_barrier();
+        for (int j1 = 16; j1 < 32; ++j1) v[j1] = load_c(rnext, load_off, j1 * 8192);     // xm[] is dead: next row, second half
+        lds_barrier();
 #pragma unroll
         for (int m = 0; m < 9; ++m) {
             if (m == 8 && wave != 0) break;                // bins past 32768 + 15 do not exist
@@ -415,21 +408,67 @@ __global__ __launch_bounds__(1024) void rfft64k_kernel(const float *__restrict__
             }
             if (m & 1) __builtin_amdgcn_sched_barrier(0);
         }
-        if (!SKIP(8)) lds_barrier();                     // plane free for the next row's exchange 1
-        STAMP(7);                                          // post-pass done, stores issued
+        lds_barrier();                                     // plane free for the next row's exchange 1
     }
 }
 
+// Inverse packed-real pre-pass in the mirrored lane layout: on entry v[a] = Y[c + 1024 a]
+// (natural row order), on exit v[a] = Z[c + 1024 a] / M.  y_last = bin M (column 0 only).
+__device__ __forceinline__ void inverse_prepass(cf (&v)[32], cf y_last, const f2 *aux, int wave_sgpr) {
+    constexpr float kScale = 1.0f / (float) kM;            // 2/(2n), dsc_fft.h:232
+    const int t1 = thread_id(wave_sgpr);
+    const int lane = t1 & 63, wave = t1 >> 6;
+    const int c = column_of(wave, lane);
+    const int partner_addr = partner_byte_addr(wave, lane);
+    // Column 0 pairs row a with row 32 - a of itself and row 0 with bin M.  Shifting its rows
+    // 17..31 down by one (bin M into row 31) turns that into the general "row a with row 31 - a
+    // of the partner" with itself as partner.
+    const cf y_mid = v[16];                                // bin M/2 pairs with itself
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 16; r < 31; ++r) v[r] = lane == 0 ? v[r + 1] : v[r];
+        v[31] = lane == 0 ? y_last : v[31];
+        if (lane == 0) { v[0].y = 0.f; v[31].y = 0.f; }    // dsc_fft.h:227-228 reads the real parts only
+    }
+    const cf wpre = to_cf(aux[kAuxW65536 + c]);
+    const cf wq_base = cf{0.5f * kScale * wpre.y, 0.5f * kScale * wpre.x};      // (i/2) conj(W^c) / M
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {                 // two batches of 8 pairs: VGPR budget
+        cf q[8], zm[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int a = half * 8 + i;
+            q[i].x = bperm(partner_addr, v[31 - a].x);
+            q[i].y = bperm(partner_addr, v[31 - a].y);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int a = half * 8 + i;
+            const cf cj = cf{root64_re(a), -root64_im(a)}; // conj(W_64^a)
+            const cf wq = a == 0 ? wq_base : cmul(wq_base, cj);
+            real_pair(v[a], q[i], wq, 0.5f * kScale, v[a], zm[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {                      // the partner finished my rows 31..16
+            const int a = half * 8 + i;
+            v[31 - a].x = bperm(partner_addr, zm[i].x);
+            v[31 - a].y = bperm(partner_addr, zm[i].y);
+        }
+    }
+    if (wave == 0) {                                       // undo the shift of column 0
+#pragma unroll
+        for (int r = 31; r > 16; --r) v[r] = lane == 0 ? v[r - 1] : v[r];
+        v[16] = lane == 0 ? cf{kScale * y_mid.x, -kScale * y_mid.y} : v[16];   // Z[M/2] = conj Y[M/2] (dsc_fft.h:218)
+    }
+}
 
 // ------------------------------------------------------------------------------------------
 // inverse: X [batch][32769] c32  ->  x [batch][65536] f32        (dsc_irfft, dsc_fft.h:194-236)
 //
 // The forward pipeline run backwards.  The bins are read in the column layout of the forward
-// post-pass (lane l and lane 63-l of a wave hold columns c and 1024-c, 32 rows k = c + 1024 a
-// each), the packed-real pre-pass Z[k] = h1 + conj(w) h2 pairs them through ds_bpermute, and
-// three conjugate-twiddle passes over (a, b, c') with k = 1024 a + 32 b + c' end with thread t
-// holding z[t + 1024 r]: the time samples leave as aligned, coalesced 8-B stores.
-// The 2/(2n) scale of the reference (dsc_fft.h:232) is folded into the pre-pass constants.
+// post-pass, the packed-real pre-pass pairs them through ds_bpermute, and three
+// conjugate-twiddle passes end with thread t holding z[t + 1024 r]: the time samples leave as
+// aligned, coalesced 8-B stores.  The 2/(2n) scale is folded into the pre-pass constants.
 __global__ __launch_bounds__(1024) void irfft64k_kernel(const f2 *__restrict__ X, float *__restrict__ x, int batch,
                                                         const f2 *__restrict__ aux) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -439,7 +478,6 @@ __global__ __launch_bounds__(1024) void irfft64k_kernel(const f2 *__restrict__ X
     __syncthreads();
 
     const int wave_sgpr = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr float kScale = 1.0f / (float) kM;
 
     for (int row = blockIdx.x; row < batch; row += gridDim.x) {
         const __amdgpu_buffer_rsrc_t rin =
@@ -454,113 +492,123 @@ __global__ __launch_bounds__(1024) void irfft64k_kernel(const f2 *__restrict__ X
             const int t0 = thread_id(wave_sgpr);
             const int c = column_of(t0 >> 6, t0 & 63);
 #pragma unroll
-            for (int a = 0; a < 32; ++a)
-                v[a] = to_cf(__builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rin, c * 8, a * 8192, 0)));
-            if (c == 0) y_last = to_cf(__builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rin, kM * 8, 0, 0)));   // bin M
+            for (int a = 0; a < 32; ++a) v[a] = load_c(rin, c * 8, a * 8192);
+            if (c == 0) y_last = load_c(rin, kM * 8, 0);   // bin M
         }
+        inverse_prepass(v, y_last, aux, wave_sgpr);
+        three_passes<true>(v, plane, w1024, aux, wave_sgpr, true, false);      // v[p] = z[t + 1024 br5(p)]
+        {
+            const int t4 = thread_id(wave_sgpr);
+#pragma unroll
+            for (int p = 0; p < 32; ++p) store_c(v[p], rout, t4 * 8, br5(p) * 8192);
+        }
+    }
+}
 
-        // ---- packed-real pre-pass (dsc_fft.h:199-228): rows 0..15 pair with rows 31..16 of the
-        // partner column.  Z[k] = s/2 + wq d,  Z[M-k] = conj(s/2 - wq d),  s = p + conj q,
-        // d = p - conj q,  wq = (i/2) conj(W_65536^k); everything pre-multiplied by 1/M.
+// ------------------------------------------------------------------------------------------
+// fused README filterFFT (README.md:113-135): y = irfft(rfft(s) * H), H [32769] c32 shared by
+// all rows.  The reference runs rfft, mul, irfft as three passes over memory with two
+// materialised spectra; here the spectrum never leaves the register file: forward passes,
+// post-pass pairs (X[k], X[M-k]), times (H[k], H[M-k]) read from L2, inverse pre-pass on the
+// same pair in the same lane, inverse passes.  4 B/sample in, 4 B/sample out.
+__global__ __launch_bounds__(1024) void filter64k_kernel(const float *__restrict__ x, const f2 *__restrict__ H,
+                                                         float *__restrict__ y, int batch, const f2 *__restrict__ aux) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *plane = lds;
+    f2 *w1024 = (f2 *) (lds + kPlaneFloats);
+    w1024[threadIdx.x] = aux[kAuxW1024 + threadIdx.x];
+    __syncthreads();
+
+    const int wave_sgpr = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void *) H, 0, (kM + 1) * 8, 0x00020000);
+    constexpr float kScale = 1.0f / (float) kM;
+
+    for (int row = blockIdx.x; row < batch; row += gridDim.x) {
+        const __amdgpu_buffer_rsrc_t rin =
+            __builtin_amdgcn_make_buffer_rsrc((void *) (x + (size_t) row * 65536), 0, 65536 * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rout =
+            __builtin_amdgcn_make_buffer_rsrc((void *) (y + (size_t) row * 65536), 0, 65536 * 4, 0x00020000);
+        cf v[32];
+        {
+            const int load_off = thread_id(wave_sgpr) * 8;
+#pragma unroll
+            for (int j1 = 0; j1 < 32; ++j1) v[j1] = load_c(rin, load_off, j1 * 8192);
+        }
+        three_passes<false>(v, plane, w1024, aux, wave_sgpr, false, true);     // v[p] = Z[c + 1024 br5(p)]
+
+        // ---- post-pass, multiply by H, pre-pass: all on the pair (k, M-k) held by this lane.
+        // In place: register br5(r) holds row r of the column before (Z) and after (Z'/M).
         {
             const int t1 = thread_id(wave_sgpr);
             const int lane = t1 & 63, wave = t1 >> 6;
             const int c = column_of(wave, lane);
-            const int partner_addr = ((wave == 0 && (lane == 63 || lane == 0)) ? lane : 63 - lane) * 4;
-            // Column 0 (lane 0 of wave 0) pairs row a with row 32 - a of itself and row 0 with bin M.
-            // Shifting its rows 17..31 down by one (and putting bin M in row 31) turns that into
-            // the general "row a with row 31 - a of the partner" with itself as partner.
-            const cf y_mid = v[16];                        // bin M/2 pairs with itself
+            const int partner_addr = partner_byte_addr(wave, lane);
+            const cf wc = to_cf(aux[kAuxW65536 + c]);
+            const cf post_base = cf{0.5f * wc.y, -0.5f * wc.x};                 // -(i/2) W^c
+            const cf pre_base = cf{0.5f * kScale * wc.y, 0.5f * kScale * wc.x}; // (i/2M) conj(W^c)
+            if (wave == 0) {                               // column 0, row 16: bin M/2 pairs with itself
+                const cf zmid = v[br5(16)];
+                const cf hmid = load_c(rh, (kM / 2) * 8, 0);
+                const cf pmid = cmul(cf{zmid.x, -zmid.y}, hmid);               // X[M/2] H[M/2]
+                v[br5(16)] = lane == 0 ? cf{kScale * pmid.x, -kScale * pmid.y} : v[br5(16)];
+            }
+            // Column 0 pairs row a with row 32 - a of itself (row 0 with itself: X[0], X[M] both come
+            // from Z[0]).  Shift its rows 17..31 down by one so that the general "row 31 - a" applies;
+            // its own row 16 result (above) is parked meanwhile.
+            cf park = v[br5(16)];
             if (wave == 0) {
 #pragma unroll
-                for (int r = 16; r < 31; ++r) v[r] = lane == 0 ? v[r + 1] : v[r];
-                v[31] = lane == 0 ? y_last : v[31];
-                if (lane == 0) { v[0].y = 0.f; v[31].y = 0.f; }         // dsc_fft.h:227-228 reads the real parts only
+                for (int r = 16; r < 31; ++r) v[br5(r)] = lane == 0 ? v[br5(r + 1)] : v[br5(r)];
+                v[br5(31)] = lane == 0 ? v[br5(0)] : v[br5(31)];
             }
-            const cf wpre = to_cf(aux[kAuxW65536 + c]);
-            const cf wq_base = cf{0.5f * kScale * wpre.y, 0.5f * kScale * wpre.x};      // (i/2) conj(W^c) / M
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {         // two batches of 8 pairs: VGPR budget
-                cf q[8], zm[8];
+            for (int part = 0; part < 8; ++part) {         // eight batches of 2 pairs: VGPR budget
+                cf q[2], zm[2];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int a = half * 8 + i;
-                    q[i].x = bperm(partner_addr, v[31 - a].x);
-                    q[i].y = bperm(partner_addr, v[31 - a].y);
+                for (int i = 0; i < 2; ++i) {
+                    const int a = part * 2 + i;
+                    q[i].x = bperm(partner_addr, v[br5(31 - a)].x);
+                    q[i].y = bperm(partner_addr, v[br5(31 - a)].y);
                 }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int a = half * 8 + i;
-                    const cf p = v[a];
-                    const cf s = cf{p.x + q[i].x, p.y - q[i].y};
-                    const cf d = cf{p.x - q[i].x, p.y + q[i].y};
-                    const cf cj = cf{root64_re(a), -root64_im(a)};       // conj(W_64^a)
-                    const cf wq = a == 0 ? wq_base : cmul(wq_base, cj);
-                    const cf wd = cmul(d, wq);
-                    v[a] = cf{0.5f * kScale * s.x + wd.x, 0.5f * kScale * s.y + wd.y};
-                    zm[i] = cf{0.5f * kScale * s.x - wd.x, wd.y - 0.5f * kScale * s.y};
+                for (int i = 0; i < 2; ++i) {
+                    const int a = part * 2 + i;
+                    const cf w64 = cf{root64_re(a), root64_im(a)};
+                    cf xk, xm;
+                    real_pair(v[br5(a)], q[i], a == 0 ? post_base : cmul(post_base, w64), 0.5f, xk, xm);
+                    // bins k = c + 1024 a and M - k, times the filter
+                    const cf hk = load_c(rh, c * 8, a * 8192);
+                    const cf hm = load_c(rh, (kM - 15 * 1024 - c) * 8, (15 - a) * 8192);
+                    cf pk = cmul(xk, hk), pm = cmul(xm, hm);
+                    if (a == 0) {                          // dsc_fft.h:227-228: bins 0 and M enter irfft through their real parts
+                        pk.y = (c == 0) ? 0.f : pk.y;
+                        pm.y = (c == 0) ? 0.f : pm.y;
+                    }
+                    const cf w64c = cf{root64_re(a), -root64_im(a)};
+                    real_pair(pk, pm, a == 0 ? pre_base : cmul(pre_base, w64c), 0.5f * kScale, v[br5(a)], zm[i]);
                 }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {              // the partner finished my rows 31..16
-                    const int a = half * 8 + i;
-                    v[31 - a].x = bperm(partner_addr, zm[i].x);
-                    v[31 - a].y = bperm(partner_addr, zm[i].y);
+                for (int i = 0; i < 2; ++i) {              // Z'[M-k] belongs to the partner's row 31 - a
+                    const int a = part * 2 + i;
+                    v[br5(31 - a)].x = bperm(partner_addr, zm[i].x);
+                    v[br5(31 - a)].y = bperm(partner_addr, zm[i].y);
                 }
+                __builtin_amdgcn_sched_barrier(0);         // keep the next batch's H loads and bpermutes out of this one
             }
             if (wave == 0) {                               // undo the shift of column 0
 #pragma unroll
-                for (int r = 31; r > 16; --r) v[r] = lane == 0 ? v[r - 1] : v[r];
-                v[16] = lane == 0 ? cf{kScale * y_mid.x, -kScale * y_mid.y} : v[16];   // Z[M/2] = conj Y[M/2] (dsc_fft.h:218)
+                for (int r = 31; r > 16; --r) v[br5(r)] = lane == 0 ? v[br5(r - 1)] : v[br5(r)];
+                v[br5(16)] = lane == 0 ? park : v[br5(16)];
             }
         }
-
-        // ---- pass 1 (over a), twiddle conj(W_1024^{b r1}), exchange 1: (b, c')[r1] -> (r1, c')[b]
-        dft32<true>(v);
-        cf u[32];
-        {
-            const int t2 = thread_id(wave_sgpr);
-            const int c = column_of(t2 >> 6, t2 & 63);
-            const int b = c >> 5;
+        cf z[32];                                          // inverse input in natural row order (a renaming)
 #pragma unroll
-            for (int r1 = 1; r1 < 32; ++r1) v[br5(r1)] = cmul_conj(v[br5(r1)], to_cf(w1024[b * r1]));
-            const int wbase1 = (c & 31) * kRowPitch + b;
-            plane_write<0>(plane, wbase1, v);
-            lds_barrier();
-            plane_read<0>(plane, t2, u);
-            lds_barrier();
-            plane_write<1>(plane, wbase1, v);
-            lds_barrier();
-            plane_read<1>(plane, t2, u);
-            lds_barrier();
-        }
-
-        // ---- pass 2 (over b), twiddle conj(W_32768^{c' r1} W_1024^{c' r2}), exchange 2 -> thread t, [c']
-        dft32<true>(u);
-        {
-            const int t3 = thread_id(wave_sgpr);
-            const int hi = t3 >> 5, lo = t3 & 31;          // (r1, c')
-            const cf tw2_base = to_cf(aux[kAuxW32768 + hi * lo]);
-            u[0] = cmul_conj(u[0], tw2_base);
-#pragma unroll
-            for (int r2 = 1; r2 < 32; ++r2) u[br5(r2)] = cmul_conj(u[br5(r2)], cmul(tw2_base, to_cf(w1024[lo * r2])));
-            const int wbase2 = hi * kRowPitch + lo;
-            plane_write<0>(plane, wbase2, u);
-            lds_barrier();
-            plane_read<0>(plane, t3, v);
-            lds_barrier();
-            plane_write<1>(plane, wbase2, u);
-            lds_barrier();
-            plane_read<1>(plane, t3, v);
-            lds_barrier();
-        }
-
-        // ---- pass 3 (over c'): v[p] = z[t + 1024 br5(p)] = (x[2j], x[2j+1])
-        dft32<true>(v);
+        for (int r = 0; r < 32; ++r) z[r] = v[br5(r)];
+        three_passes<true>(z, plane, w1024, aux, wave_sgpr, true, false);      // z[p] = y[2(t + 1024 br5(p)) .. +1]
         {
             const int t4 = thread_id(wave_sgpr);
 #pragma unroll
-            for (int p = 0; p < 32; ++p)
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, to_f2(v[p])), rout, t4 * 8, br5(p) * 8192, 0);
+            for (int p = 0; p < 32; ++p) store_c(z[p], rout, t4 * 8, br5(p) * 8192);
         }
     }
 }
@@ -609,4 +657,13 @@ void dsc_launch_irfft64k(const void *X, float *x, int batch, const void *aux, in
     const int grid = batch < n_cu ? batch : n_cu;
     hipLaunchKernelGGL(irfft64k_kernel, dim3(grid), dim3(1024), kLdsBytes, stream, (const f2 *) X, x, batch, (const f2 *) aux);
 }
-void dsc_launch_filter64k(const float *, const void *, float *, int, const void *, int, hipStream_t) {}
+void dsc_launch_filter64k(const float *s, const void *H, float *y, int batch, const void *aux, int n_cu, hipStream_t stream) {
+    if (batch <= 0) return;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void) hipFuncSetAttribute((const void *) filter64k_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        attr_set = true;
+    }
+    const int grid = batch < n_cu ? batch : n_cu;
+    hipLaunchKernelGGL(filter64k_kernel, dim3(grid), dim3(1024), kLdsBytes, stream, s, (const f2 *) H, y, batch, (const f2 *) aux);
+}
