@@ -1,0 +1,145 @@
+"""GPU tests of the register-resident 65536-point kernels (the hot path of BASELINE.json):
+parity against the CPU oracle on seeded rows, and — at BASELINE's full sizes, where the oracle
+would take minutes — size-independent properties: round trip, linearity, Parseval, impulse /
+tone known answers, and agreement of a random sample of rows with the oracle.  All through the
+C ABI.  Tolerance: rel-L2 <= 1e-5 (north_star)."""
+import numpy as np
+import pytest
+
+from tests.helpers import assert_close, rel_l2
+
+pytestmark = pytest.mark.gpu
+N = 65536
+
+
+@pytest.fixture(scope='module')
+def dsc():
+    import dsc_amd
+    try:
+        dsc_amd.init(12 << 30, 4 << 30)
+    except RuntimeWarning:
+        pass
+    yield dsc_amd
+    dsc_amd.synchronize()
+
+
+def test_paths_are_the_hand_written_kernels(dsc):
+    x = dsc.from_numpy(np.ones((2, N), np.float32))
+    X = dsc.rfft(x)
+    assert dsc.last_fft_path() == 'r2c_64k_regs'
+    dsc.irfft(X)
+    assert dsc.last_fft_path() == 'c2r_64k_regs'
+    H = dsc.from_numpy(np.ones(N // 2 + 1, np.complex64))
+    dsc.filter_fft(x, H)
+    assert dsc.last_fft_path() == 'filter_64k_regs'
+    # anything the fast kernels do not cover must still be right through the generic path
+    dsc.rfft(dsc.from_numpy(np.ones((2, 60000), np.float32)))          # zero-padded rows
+    assert dsc.last_fft_path() == 'generic_4step'
+
+
+@pytest.mark.parametrize('rows', [1, 2, 17, 255, 257, 600])
+def test_rfft_irfft_vs_oracle_all_row_skews(dsc, rows):
+    """Output rows are 32769 bins long: every row has a different alignment (row mod 16) in the
+    aligned-store staging, and grids smaller / larger than the 256 CUs take different loops."""
+    from oracle import port
+    rng = np.random.default_rng(rows)
+    x = rng.standard_normal((rows, N)).astype(np.float32)
+    X = dsc.rfft(dsc.from_numpy(x))
+    got = X.numpy()
+    pick = sorted(set([0, rows - 1] + list(rng.integers(0, rows, 6))))
+    for r in pick:
+        assert_close(got[r], port.rfft(x[r]), what=f'rfft row {r}/{rows}')
+    truth = np.fft.rfft(x.astype(np.float64), axis=-1)
+    assert rel_l2(got, truth) <= 1e-6                      # every row, against float64 numpy
+    assert np.all(got[:, 0].imag == 0) and np.all(got[:, -1].imag == 0)     # dsc_fft.h:221-225
+    back = dsc.irfft(X).numpy()
+    for r in pick:
+        assert_close(back[r], port.irfft(got[r]), what=f'irfft row {r}/{rows}')
+    assert rel_l2(back, x) <= 1e-6
+
+
+def test_irfft_ignores_imag_of_dc_and_nyquist(dsc):
+    """dsc_fft.h:227-228 reads only the real parts of bins 0 and n."""
+    from oracle import port
+    rng = np.random.default_rng(3)
+    X = (rng.standard_normal((3, N // 2 + 1)) + 1j * rng.standard_normal((3, N // 2 + 1))).astype(np.complex64)
+    assert_close(dsc.irfft(dsc.from_numpy(X)).numpy(), port.irfft(X))
+
+
+def test_known_answers(dsc):
+    t = np.arange(N)
+    x = np.zeros((5, N), np.float32)
+    x[0, 0] = 1                                            # impulse -> all ones
+    x[1, 7] = 1                                            # shifted impulse -> exp(-2 pi i 7 k / N)
+    x[2] = 1                                               # constant -> N at DC
+    x[3] = np.cos(2 * np.pi * 1234 * t / N)                # tone -> N/2 at bin 1234
+    x[4] = np.cos(np.pi * t)                               # Nyquist -> N at bin N/2
+    X = dsc.rfft(dsc.from_numpy(x)).numpy().astype(np.complex128)
+    k = np.arange(N // 2 + 1)
+    assert np.max(np.abs(X[0] - 1)) < 1e-5
+    assert np.max(np.abs(X[1] - np.exp(-2j * np.pi * 7 * k / N))) < 1e-5
+    want = np.zeros(N // 2 + 1); want[0] = N
+    assert np.max(np.abs(X[2] - want)) < 1e-5 * N
+    want = np.zeros(N // 2 + 1); want[1234] = N / 2
+    assert np.max(np.abs(X[3] - want)) < 1e-5 * N
+    want = np.zeros(N // 2 + 1); want[N // 2] = N
+    assert np.max(np.abs(X[4] - want)) < 1e-5 * N
+
+
+def test_fused_filter_vs_composition(dsc, golden):
+    from oracle import port
+    rng = np.random.default_rng(8)
+    taps = 537
+    tt = np.arange(taps) - (taps - 1) / 2
+    b = np.zeros(N, np.float32)
+    b[:taps] = (np.sinc(0.2 * tt) * np.hamming(taps) * 0.2).astype(np.float32)
+    Hh = port.rfft(b)
+    Hh[0] += 0.25j                                         # the product's imaginary DC part must be ignored
+    for rows in (1, 3, 300):
+        s = rng.standard_normal((rows, N)).astype(np.float32)
+        got = dsc.filter_fft(dsc.from_numpy(s), dsc.from_numpy(Hh)).numpy()
+        assert dsc.last_fft_path() == 'filter_64k_regs'
+        want = port.irfft(port.mul(port.rfft(s[:3]), Hh))
+        assert_close(got[:3], want, what=f'fused filter rows={rows}')
+        comp = dsc.irfft(dsc.rfft(dsc.from_numpy(s)) * dsc.from_numpy(Hh)).numpy()
+        assert rel_l2(got, comp) <= 2e-6
+    # the README pipeline's golden case (65000-sample signal, 537 taps), zero-padded by hand
+    for rec, xs, y in golden.cases('filter'):
+        if rec['n'] != N:
+            continue
+        s = np.zeros(N, np.float32); s[:len(xs[0])] = xs[0]
+        bb = np.zeros(N, np.float32); bb[:len(xs[1])] = xs[1]
+        got = dsc.filter_fft(dsc.from_numpy(s), dsc.rfft(dsc.from_numpy(bb))).numpy()
+        assert_close(got, y, what='README filterFFT golden through the fused kernel')
+
+
+def test_full_size_properties(dsc):
+    """BASELINE configs[1]: [8192, 65536] f32 (2 GiB in, 2 GiB out)."""
+    from oracle import port
+    B = 8192
+    rng = np.random.default_rng(1234)
+    x = rng.standard_normal((B, N), dtype=np.float32)
+    xd = dsc.from_numpy(x)
+    X = dsc.rfft(xd)
+    assert dsc.last_fft_path() == 'r2c_64k_regs'
+    Xh = X.numpy()
+    # (1) a sample of rows against the oracle
+    for r in [0, 1, 255, 256, 4095, 8191] + list(rng.integers(0, B, 10)):
+        assert_close(Xh[r], port.rfft(x[r]), what=f'full-size row {r}')
+    # (2) Parseval on every row: sum |x|^2 = (|X0|^2 + |XM|^2 + 2 sum |Xk|^2) / N
+    e_t = np.sum(x.astype(np.float64) ** 2, axis=1)
+    p = np.abs(Xh.astype(np.complex128)) ** 2
+    e_f = (p[:, 0] + p[:, -1] + 2 * np.sum(p[:, 1:-1], axis=1)) / N
+    assert np.max(np.abs(e_f - e_t) / e_t) < 1e-5
+    # (3) round trip on every row
+    back = dsc.irfft(X)
+    assert dsc.last_fft_path() == 'c2r_64k_regs'
+    bh = back.numpy()
+    assert rel_l2(bh, x) <= 1e-6 and np.max(np.abs(bh - x)) < 1e-4
+    del back, bh
+    # (4) linearity: rfft(2 x + roll(x)) = 2 X + rfft(roll(x)) on a slice of the batch
+    a = x[:512]
+    r = np.roll(a, 1, axis=0)
+    lhs = dsc.rfft(dsc.from_numpy(2 * a + r)).numpy()
+    rhs = 2 * Xh[:512] + dsc.rfft(dsc.from_numpy(r)).numpy()
+    assert rel_l2(lhs, rhs) <= 2e-6
