@@ -1,7 +1,8 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): bench line, rocprofv3 kernel-trace stats, and the two PMC
-# passes for HBM bytes (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950).
-# Usage: tools/profile_bench.sh <tag>     -> gpurun_out/<tag>/...
+# Runs on the GPU box (via gpurun): the bench line, the rocprofv3 kernel-trace stats of the same
+# command, the two PMC passes for HBM bytes (FETCH_SIZE and WRITE_SIZE cannot share a pass on
+# gfx950) and the same two passes on a known-byte-count kernel for calibration.
+# Usage: tools/profile_bench.sh <tag>     -> gpurun_out/<tag>/ ; summaries -> gpurun_out/<tag>/summary.*
 set -o pipefail
 TAG=${1:-r01}
 OUT=gpurun_out/$TAG
@@ -9,7 +10,9 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 python3 bench.py --steps 50 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err || { tail -20 $OUT/bench.err; exit 1; }
 cat $OUT/bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/trace_bench.json 2> $OUT/trace.err || { tail -20 $OUT/trace.err; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/trace_bench.json 2> $OUT/trace.err || { tail -20 $OUT/trace.err; exit 1; }
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_fetch.err || { tail -20 $OUT/pmc_fetch.err; exit 1; }
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_write.err || { tail -20 $OUT/pmc_write.err; exit 1; }
-find $OUT -name "*.csv" | head -20
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/cal_fetch -- tools/bin/calib_copy > /dev/null 2> $OUT/cal_fetch.err || { tail -20 $OUT/cal_fetch.err; exit 1; }
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/cal_write -- tools/bin/calib_copy > /dev/null 2> $OUT/cal_write.err || { tail -20 $OUT/cal_write.err; exit 1; }
+python3 tools/summarize_profile.py $OUT
