@@ -144,18 +144,36 @@ static void lines_of(const dsc_tensor *t, int slot, long long *n_lines, long lon
 
 static void run_four_step(dsc_ctx *ctx, const fft_job &j, bool sp, const dsc_fft_plan *real_plan) {
     const int lds_max = dsc_fft_lds_max_len(sp);
-    const int L = j.L, L2 = lds_max, L1 = L / L2;
-    DSC_ASSERT(L1 >= 2 && L1 <= lds_max);
+    const int L = j.L;
+    // balanced split L = L1 * L2 (columns of length L1, then rows of length L2): both passes then
+    // move >= 128-B pieces when their tiles take a cache line of neighbouring lines
+    int log2l = 0;
+    while ((1 << log2l) < L) ++log2l;
+    int L1 = 1 << ((log2l + 1) / 2), L2 = L / L1;
+    while (L1 > lds_max) { L1 >>= 1; L2 <<= 1; }
+    DSC_ASSERT(L1 >= 2 && L2 >= 2 && L2 <= lds_max);
     const dsc_dtype cdt = sp ? DSC_C32 : DSC_C64;
     const dsc_fft_plan *p1 = dsc_plan_fft(ctx, L1, DSC_FFT_COMPLEX, cdt);
     const dsc_fft_plan *p2 = dsc_plan_fft(ctx, L2, DSC_FFT_COMPLEX, cdt);
+    // W_L^m for the inter-pass twiddle: the COMPLEX plan of the full length (its table is gathered
+    // from L2; computing it with sincospi in double cost more than the butterflies)
+    const dsc_fft_plan *pl = L <= (1 << 22) ? dsc_plan_fft(ctx, L, DSC_FFT_COMPLEX, cdt) : nullptr;
 
     long long n_lines, inner_in, inner_out;
     dsc_line_layout lin, lout;
     lines_of(j.x, j.slot, &n_lines, &inner_in, &lin);
     lines_of(j.out, j.slot, &n_lines, &inner_out, &lout);
 
-    const size_t line_bytes = (size_t) L * dsc_dtype_size(cdt);
+    const size_t csz = dsc_dtype_size(cdt);
+    const size_t line_bytes = (size_t) L * csz;
+    // Contiguous rows that need no padding can be read / written in place as arrays of complex:
+    //   R2C: the 2L reals of a row ARE L packed complex samples;  C2R: likewise on the way out
+    const int x_n = j.x->shape[j.slot], out_n = j.out->shape[j.slot];
+    const bool direct_in = inner_in == 1 &&
+        ((j.mode == DSC_MODE_R2C_PACKED && j.in_len == 2 * L && x_n == 2 * L) || (j.mode == DSC_MODE_C2C && j.in_len == L && x_n == L));
+    const bool direct_out = inner_out == 1 &&
+        ((j.mode == DSC_MODE_C2R_PACKED && out_n == 2 * L) || ((j.mode == DSC_MODE_C2C || j.mode == DSC_MODE_R2C_CAST) && out_n == L));
+
     ctx->scratch.reset();
     long long chunk = (long long) ((ctx->scratch.capacity() - 2 * DSC_DEVICE_ALIGN) / (2 * line_bytes));
     if (chunk < 1)
@@ -166,30 +184,36 @@ static void run_four_step(dsc_ctx *ctx, const fft_job &j, bool sp, const dsc_fft
 
     for (long long q = 0; q < n_lines; q += chunk) {
         const long long nl = n_lines - q < chunk ? n_lines - q : chunk;
-        if (j.mode == DSC_MODE_C2R_PACKED)
+        const char *src = A;
+        if (direct_in) {
+            src = (const char *) j.x->data + (size_t) q * line_bytes;
+        } else if (j.mode == DSC_MODE_C2R_PACKED) {
             dsc_launch_fft_c2r_prepass(j.x->data, A, q, nl, inner_in, lin, L, j.in_len, real_plan->tw_real, sp, ctx->stream);
-        else
+        } else {
             dsc_launch_fft_pack(j.x->data, A, q, nl, inner_in, lin, L, j.in_len, j.mode, sp, ctx->stream);
+        }
 
         dsc_fft_lines_args a;
         // columns: L2 lines of length L1 per transform, times W_L^{j2 k1}
-        a.in = A; a.out = B;
+        a.in = src; a.out = B;
         a.n_lines = nl * L2; a.inner = L2;
         a.lin = a.lout = dsc_line_layout{L, 1, L2};
         a.L = L1; a.in_len = L1; a.inverse = j.inverse; a.scale = 1.0;
-        a.tw = p1->tw_full; a.tw_real = nullptr; a.tw4_len = L;
+        a.tw = p1->tw_full; a.tw_real = nullptr; a.tw4_len = L; a.tw4 = pl ? pl->tw_full : nullptr;
         dsc_launch_fft_lines(a, DSC_MODE_C2C, sp, ctx->stream);
         // rows: L1 lines of length L2, output k1 + L1 k2
-        a.in = B; a.out = A;
+        char *dst = direct_out ? (char *) j.out->data + (size_t) q * line_bytes : A;
+        a.in = B; a.out = dst;
         a.n_lines = nl * L1; a.inner = L1;
         a.lin = dsc_line_layout{L, L2, 1};
         a.lout = dsc_line_layout{L, 1, L1};
-        a.L = L2; a.in_len = L2; a.tw = p2->tw_full; a.tw4_len = 0;
+        a.L = L2; a.in_len = L2; a.tw = p2->tw_full; a.tw4_len = 0; a.tw4 = nullptr;
+        a.scale = direct_out ? j.scale : 1.0;
         dsc_launch_fft_lines(a, DSC_MODE_C2C, sp, ctx->stream);
 
         if (j.mode == DSC_MODE_R2C_PACKED)
             dsc_launch_fft_r2c_postpass(A, j.out->data, q, nl, inner_out, lout, L, real_plan->tw_real, sp, ctx->stream);
-        else
+        else if (!direct_out)
             dsc_launch_fft_unpack(A, j.out->data, q, nl, inner_out, lout, L, j.scale, j.mode, sp, ctx->stream);
     }
     ctx->last_fft_path = "generic_4step";
@@ -225,7 +249,7 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
         a.n_lines = n_lines; a.inner = inner;
         a.lin = lin; a.lout = lout;
         a.L = j.L; a.in_len = j.in_len; a.inverse = j.inverse; a.scale = j.scale;
-        a.tw = plan->tw_full; a.tw_real = plan->tw_real; a.tw4_len = 0;
+        a.tw = plan->tw_full; a.tw_real = plan->tw_real; a.tw4_len = 0; a.tw4 = nullptr;
         dsc_launch_fft_lines(a, j.mode, sp, ctx->stream);
         ctx->last_fft_path = "generic_lds";
         return;

@@ -23,7 +23,7 @@
 
 namespace {
 
-constexpr int kThreads = 256;
+constexpr int kMaxThreads = 1024;           // block size is chosen per launch: 64 .. 1024 threads
 constexpr int kTileBytes = 72 * 1024;        // per LDS image; two images per workgroup (144 of 160 KiB)
 
 template<typename T> struct alignas(2 * sizeof(T)) cx { T x, y; };
@@ -71,57 +71,94 @@ struct lines_params {
     int L, in_len, inverse;
     int C, P;                 // lines per tile, LDS row pitch (complex elements)
     T scale;
-    const cx<T> *tw, *tw_real;
+    const cx<T> *tw, *tw_real, *tw4;
     long long tw4_len;
 };
 
+// Division-free walk over the (line, element) pairs of a tile.  The block (a power of two) is
+// split TC x TE with both factors powers of two; neighbouring threads take neighbouring
+// ELEMENTS when the element stride is 1 in memory, neighbouring LINES otherwise.
+struct tile_walk {
+    int tc, te, TC, TE;
+};
+__device__ __forceinline__ int pow2_ceil(int x) { return x <= 1 ? 1 : 1 << (32 - __clz(x - 1)); }
+__device__ __forceinline__ tile_walk make_walk(int tid, int threads, int nl, int per_line, bool elem_major) {
+    tile_walk w;
+    if (elem_major) {
+        const int te_n = pow2_ceil(per_line);
+        w.TE = te_n < threads ? te_n : threads;
+        w.TC = threads / w.TE;
+        w.te = tid & (w.TE - 1);
+        w.tc = tid >> (31 - __clz(w.TE));
+    } else {
+        const int tc_n = pow2_ceil(nl);
+        w.TC = tc_n < threads ? tc_n : threads;
+        w.TE = threads / w.TC;
+        w.tc = tid & (w.TC - 1);
+        w.te = tid >> (31 - __clz(w.TC));
+    }
+    return w;
+}
+
 template<typename T, int MODE>
-__global__ __launch_bounds__(kThreads) void fft_lines_kernel(const lines_params<T> p) {
+__global__ __launch_bounds__(kMaxThreads) void fft_lines_kernel(const lines_params<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using C = cx<T>;
     const int tid = threadIdx.x;
+    const int threads = blockDim.x;
     const int L = p.L, P = p.P;
+    const int log2L = 31 - __clz(L);
     const long long q0 = (long long) blockIdx.x * p.C;
     const int nl = (int) (p.n_lines - q0 < p.C ? p.n_lines - q0 : p.C);
 
     C *src = (C *) smem;
     C *dst = src + (size_t) p.C * P;
+    // per-line bases, computed once per tile (64-bit divisions are expensive)
+    long long *base_in = (long long *) (dst + (size_t) p.C * P);
+    long long *base_out = base_in + p.C;
+    int *line_in_group = (int *) (base_out + p.C);
+    for (int c = tid; c < nl; c += threads) {
+        const long long q = q0 + c;
+        const long long o = q / p.inner, i = q - o * p.inner;
+        base_in[c] = o * p.lin.outer_stride + i * p.lin.inner_stride;
+        base_out[c] = o * p.lout.outer_stride + i * p.lout.inner_stride;
+        line_in_group[c] = (int) i;
+    }
+    __syncthreads();
 
     // ---------------------------------------------------------------- gather
     {
         const int per_line = (MODE == DSC_MODE_C2R_PACKED) ? L + 1 : L;
-        const int total = nl * per_line;
-        const bool elem_major = p.lin.elem_stride == 1 || nl == 1;
-        for (int idx = tid; idx < total; idx += kThreads) {
-            int c, e;
-            if (elem_major) { c = idx / per_line; e = idx - c * per_line; }
-            else            { e = idx / nl;       c = idx - e * nl; }
-            const long long base = line_base(q0 + c, p.inner, p.lin);
-            C v = {(T) 0, (T) 0};
-            if (MODE == DSC_MODE_C2C || MODE == DSC_MODE_C2R_PACKED) {
-                if (e < p.in_len) v = ((const C *) p.in)[base + (long long) e * p.lin.elem_stride];
-            } else if (MODE == DSC_MODE_R2C_CAST) {
-                if (e < p.in_len) v.x = ((const T *) p.in)[base + (long long) e * p.lin.elem_stride];
-            } else {    // R2C_PACKED: complex sample e = (x[2e], x[2e+1])
-                const T *x = (const T *) p.in;
-                const int r = 2 * e;
-                if (p.lin.elem_stride == 1 && ((base & 1) == 0) && r + 1 < p.in_len) {
-                    v = *(const C *) (x + base + r);
-                } else {
-                    if (r < p.in_len)     v.x = x[base + (long long) r * p.lin.elem_stride];
-                    if (r + 1 < p.in_len) v.y = x[base + (long long) (r + 1) * p.lin.elem_stride];
+        const tile_walk w = make_walk(tid, threads, nl, per_line, p.lin.elem_stride == 1 || nl == 1);
+        for (int c = w.tc; c < nl; c += w.TC) {
+            const long long base = base_in[c];
+            for (int e = w.te; e < per_line; e += w.TE) {
+                C v = {(T) 0, (T) 0};
+                if (MODE == DSC_MODE_C2C || MODE == DSC_MODE_C2R_PACKED) {
+                    if (e < p.in_len) v = ((const C *) p.in)[base + (long long) e * p.lin.elem_stride];
+                } else if (MODE == DSC_MODE_R2C_CAST) {
+                    if (e < p.in_len) v.x = ((const T *) p.in)[base + (long long) e * p.lin.elem_stride];
+                } else {    // R2C_PACKED: complex sample e = (x[2e], x[2e+1])
+                    const T *x = (const T *) p.in;
+                    const int r = 2 * e;
+                    if (p.lin.elem_stride == 1 && ((base & 1) == 0) && r + 1 < p.in_len) {
+                        v = *(const C *) (x + base + r);
+                    } else {
+                        if (r < p.in_len)     v.x = x[base + (long long) r * p.lin.elem_stride];
+                        if (r + 1 < p.in_len) v.y = x[base + (long long) (r + 1) * p.lin.elem_stride];
+                    }
                 }
+                src[c * P + e] = v;
             }
-            src[c * P + e] = v;
         }
         __syncthreads();
     }
 
     // ---------------------------------------------------------------- irfft pre-pass
     if (MODE == DSC_MODE_C2R_PACKED) {
-        const int total = nl * L;
-        for (int idx = tid; idx < total; idx += kThreads) {
-            const int c = idx / L, k = idx - c * L;
+        const int total = nl << log2L;
+        for (int idx = tid; idx < total; idx += threads) {
+            const int c = idx >> log2L, k = idx & (L - 1);
             C a = src[c * P + k], b = src[c * P + L - k];
             if (k == 0) { a.y = (T) 0; b.y = (T) 0; }     // dsc_fft.h:227-228 reads real parts only
             dst[c * P + k] = c2r_bin(a, b, p.tw_real[k]);
@@ -137,12 +174,11 @@ __global__ __launch_bounds__(kThreads) void fft_lines_kernel(const lines_params<
     // (natural order in, natural order out; no bit reversal).
     {
         int Ns = 1;
-        int log2L = 31 - __clz(L);
         if (log2L & 1) {                                  // one radix-2 stage first (Ns = 1: no twiddle)
             const int half = L >> 1;
-            const int items = nl * half;
-            for (int w = tid; w < items; w += kThreads) {
-                const int c = w / half, j = w - c * half;
+            const int items = nl << (log2L - 1);
+            for (int w = tid; w < items; w += threads) {
+                const int c = w >> (log2L - 1), j = w & (half - 1);
                 const C a = src[c * P + j], b = src[c * P + j + half];
                 dst[c * P + 2 * j]     = cadd(a, b);
                 dst[c * P + 2 * j + 1] = csub(a, b);
@@ -154,10 +190,10 @@ __global__ __launch_bounds__(kThreads) void fft_lines_kernel(const lines_params<
         const T sgn = p.inverse ? (T) -1 : (T) 1;
         for (; Ns < L; Ns <<= 2) {
             const int quarter = L >> 2;
-            const int items = nl * quarter;
+            const int items = nl << (log2L - 2);
             const int tw_step = L / (Ns << 2);
-            for (int w = tid; w < items; w += kThreads) {
-                const int c = w / quarter, j = w - c * quarter;
+            for (int w = tid; w < items; w += threads) {
+                const int c = w >> (log2L - 2), j = w & (quarter - 1);
                 const int k = j & (Ns - 1);
                 const C *s = src + c * P + j;
                 C v0 = s[0], v1 = s[quarter], v2 = s[2 * quarter], v3 = s[3 * quarter];
@@ -182,52 +218,47 @@ __global__ __launch_bounds__(kThreads) void fft_lines_kernel(const lines_params<
 
     // ---------------------------------------------------------------- scatter
     if (MODE == DSC_MODE_C2C || MODE == DSC_MODE_R2C_CAST) {
-        const int total = nl * L;
-        const bool elem_major = p.lout.elem_stride == 1 || nl == 1;
-        for (int idx = tid; idx < total; idx += kThreads) {
-            int c, k;
-            if (elem_major) { c = idx / L;  k = idx - c * L; }
-            else            { k = idx / nl; c = idx - k * nl; }
-            const long long q = q0 + c;
-            C v = src[c * P + k];
-            if (p.tw4_len) {
-                C w = unit_root<T>((q % p.inner) * (long long) k, p.tw4_len);
-                if (p.inverse) w.y = -w.y;
-                v = cmul(v, w);
+        const tile_walk w = make_walk(tid, threads, nl, L, p.lout.elem_stride == 1 || nl == 1);
+        for (int c = w.tc; c < nl; c += w.TC) {
+            const long long base = base_out[c];
+            const long long grp = line_in_group[c];
+            for (int k = w.te; k < L; k += w.TE) {
+                C v = src[c * P + k];
+                if (p.tw4_len) {
+                    C tw = p.tw4 ? p.tw4[grp * k] : unit_root<T>(grp * k, p.tw4_len);
+                    if (p.inverse) tw.y = -tw.y;
+                    v = cmul(v, tw);
+                }
+                v.x *= p.scale; v.y *= p.scale;
+                ((C *) p.out)[base + (long long) k * p.lout.elem_stride] = v;
             }
-            v.x *= p.scale; v.y *= p.scale;
-            ((C *) p.out)[line_base(q, p.inner, p.lout) + (long long) k * p.lout.elem_stride] = v;
         }
     } else if (MODE == DSC_MODE_R2C_PACKED) {
-        const int bins = L + 1;
-        const int total = nl * bins;
-        const bool elem_major = p.lout.elem_stride == 1 || nl == 1;
-        for (int idx = tid; idx < total; idx += kThreads) {
-            int c, k;
-            if (elem_major) { c = idx / bins; k = idx - c * bins; }
-            else            { k = idx / nl;   c = idx - k * nl; }
-            const C a = src[c * P + (k == L ? 0 : k)];
-            const C b = src[c * P + (k == 0 ? 0 : L - k)];
-            C v = r2c_bin(a, b, p.tw_real[k]);
-            if (k == 0 || k == L) v.y = (T) 0;               // dsc_fft.h:221-225 stores exact zeros
-            ((C *) p.out)[line_base(q0 + c, p.inner, p.lout) + (long long) k * p.lout.elem_stride] = v;
+        const tile_walk w = make_walk(tid, threads, nl, L + 1, p.lout.elem_stride == 1 || nl == 1);
+        for (int c = w.tc; c < nl; c += w.TC) {
+            const long long base = base_out[c];
+            for (int k = w.te; k <= L; k += w.TE) {
+                const C a = src[c * P + (k == L ? 0 : k)];
+                const C b = src[c * P + (k == 0 ? 0 : L - k)];
+                C v = r2c_bin(a, b, p.tw_real[k]);
+                if (k == 0 || k == L) v.y = (T) 0;           // dsc_fft.h:221-225 stores exact zeros
+                ((C *) p.out)[base + (long long) k * p.lout.elem_stride] = v;
+            }
         }
     } else {    // C2R_PACKED: 2L reals = the L complex samples, scaled (dsc_fft.h:232-236)
-        const int total = nl * L;
-        const bool elem_major = p.lout.elem_stride == 1 || nl == 1;
+        const tile_walk w = make_walk(tid, threads, nl, L, p.lout.elem_stride == 1 || nl == 1);
         T *out = (T *) p.out;
-        for (int idx = tid; idx < total; idx += kThreads) {
-            int c, k;
-            if (elem_major) { c = idx / L;  k = idx - c * L; }
-            else            { k = idx / nl; c = idx - k * nl; }
-            C v = src[c * P + k];
-            v.x *= p.scale; v.y *= p.scale;
-            const long long base = line_base(q0 + c, p.inner, p.lout);
-            if (p.lout.elem_stride == 1 && ((base & 1) == 0)) {
-                *(C *) (out + base + 2 * k) = v;
-            } else {
-                out[base + (long long) (2 * k) * p.lout.elem_stride]     = v.x;
-                out[base + (long long) (2 * k + 1) * p.lout.elem_stride] = v.y;
+        for (int c = w.tc; c < nl; c += w.TC) {
+            const long long base = base_out[c];
+            for (int k = w.te; k < L; k += w.TE) {
+                C v = src[c * P + k];
+                v.x *= p.scale; v.y *= p.scale;
+                if (p.lout.elem_stride == 1 && ((base & 1) == 0)) {
+                    *(C *) (out + base + 2 * k) = v;
+                } else {
+                    out[base + (long long) (2 * k) * p.lout.elem_stride]     = v.x;
+                    out[base + (long long) (2 * k + 1) * p.lout.elem_stride] = v.y;
+                }
             }
         }
     }
@@ -243,22 +274,33 @@ void launch_lines(const dsc_fft_lines_args &a, dsc_fft_mode mode, hipStream_t st
     p.scale = (T) a.scale;
     p.tw = (const cx<T> *) a.tw; p.tw_real = (const cx<T> *) a.tw_real;
     p.tw4_len = a.tw4_len;
+    p.tw4 = (const cx<T> *) a.tw4;
     p.P = a.L + 2;                                             // room for bin L; keeps rows 16-B aligned
-    // Lines per tile: as many as one LDS image holds, but never so many that a large batch
-    // collapses into fewer than ~1024 tiles, and never so few that a tile has < 1024 points.
-    const long long cap_c = (kTileBytes / (long long) sizeof(cx<T>)) / p.P > 0 ? (kTileBytes / (long long) sizeof(cx<T>)) / p.P : 1;
-    const long long fill_c = (a.n_lines + 1023) / 1024;
-    const long long min_c = (1024 + a.L - 1) / a.L;
-    long long C = fill_c > min_c ? fill_c : min_c;
+    // Tile = C lines.  Small tiles (<= 16 KiB per LDS image) so that several workgroups share
+    // a CU (occupancy hides the gather/scatter latency); a line that is longer than that gets a
+    // tile of its own and more threads instead.  Never fewer than ~1024 points per tile when
+    // the batch has them.
+    const long long image_cap = kTileBytes / (long long) sizeof(cx<T>);
+    const long long cap_c = image_cap / p.P > 0 ? image_cap / p.P : 1;
+    long long C = (16 * 1024 / (long long) sizeof(cx<T>)) / p.P;
+    long long min_c = (1024 + a.L - 1) / a.L;
+    // lines that are strided in memory (columns of a four-step, non-last axes) are coalesced ACROSS
+    // the lines of a tile: take at least one 128-B cache line worth of neighbours
+    const long long line_c = 128 / (long long) sizeof(cx<T>);
+    if ((a.lin.elem_stride != 1 || a.lout.elem_stride != 1) && min_c < line_c) min_c = line_c;
+    if (C < min_c) C = min_c;
+    if (C < 1) C = 1;
     if (C > cap_c) C = cap_c;
     if (C > a.n_lines) C = a.n_lines;
     p.C = (int) C;
+    const long long points = C * a.L;
+    const int threads = points <= 256 ? 64 : points <= 2048 ? 256 : points <= 8192 ? 512 : 1024;
     const long long tiles = (a.n_lines + C - 1) / C;
-    const size_t lds = 2 * (size_t) p.C * p.P * sizeof(cx<T>);
-    dim3 grid((unsigned) tiles), block(kThreads);
+    const size_t lds = 2 * (size_t) p.C * p.P * sizeof(cx<T>) + (size_t) p.C * 20;      // two images + per-line base tables
+    dim3 grid((unsigned) tiles), block(threads);
     static bool attr_set = false;          // dynamic LDS above 64 KiB must be opted into, once per kernel
     if (!attr_set) {
-        const int max_lds = 2 * kTileBytes;
+        const int max_lds = 2 * kTileBytes + 8192;
         (void) hipFuncSetAttribute((const void *) fft_lines_kernel<T, DSC_MODE_C2C>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
         (void) hipFuncSetAttribute((const void *) fft_lines_kernel<T, DSC_MODE_R2C_CAST>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
         (void) hipFuncSetAttribute((const void *) fft_lines_kernel<T, DSC_MODE_R2C_PACKED>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);

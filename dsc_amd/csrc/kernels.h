@@ -38,6 +38,7 @@ struct dsc_fft_lines_args {
     const void *tw;        // W_L^k, k in [0, L)       interleaved (cos, sin), precision of the transform
     const void *tw_real;   // W_{2L}^k, k in [0, L]    (packed modes only)
     long long tw4_len;     // four-step: also multiply output k of line q by W_{tw4_len}^{(q % inner) * k}; 0 = off
+    const void *tw4;       // table W_{tw4_len}^m, m in [0, tw4_len) (gathered, L2 resident); NULL = sincospi in double
 };
 
 // Largest complex length the LDS line kernel handles for the given precision.
