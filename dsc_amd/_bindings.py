@@ -10,7 +10,8 @@ from ctypes import POINTER, Structure, c_bool, c_char_p, c_double, c_float, c_in
 _DSC_MAX_DIMS = 4
 _DscCtx = c_void_p
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libdsc_mi355x.so')
+# DSC_MI355X_LIB overrides the library path (A/B timing of two builds on the same box)
+LIB_PATH = os.environ.get('DSC_MI355X_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libdsc_mi355x.so')
 if not os.path.exists(LIB_PATH):
     raise RuntimeError(
         f'DSC MI355X backend: "{LIB_PATH}" not built. Run `make -C dsc_amd/csrc` '
