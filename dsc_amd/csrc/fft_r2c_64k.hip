@@ -487,31 +487,76 @@ __global__ __launch_bounds__(1024) void irfft64k_kernel(const f2 *__restrict__ X
 
     const int wave_sgpr = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
+    // Software pipelined like the forward kernel: the time samples leave through the LDS
+    // staging area (whole lines, 16 B per lane) and the next row's bins are requested as soon
+    // as the staging writes have freed the registers, ahead of this row's stores.
+    // Loads keep the default cache policy: spectrum rows are skewed by 8 B x row, so neighbouring
+    // waves share their boundary lines (nt loads measured 5 % slower on this kernel).
+    cf v[32];
+    cf y_last = cf{0.f, 0.f};
+    {
+        const int row0 = blockIdx.x;
+        const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(
+            (void *) (X + (size_t) row0 * (kM + 1)), 0, row0 < batch ? (kM + 1) * 8 : 0, 0x00020000);
+        const int t0 = thread_id(wave_sgpr);
+        const int c = column_of(t0 >> 6, t0 & 63);
+#pragma unroll
+        for (int a = 0; a < 32; ++a) v[a] = load_c_cached(r0, c * 8, a * 8192);     // Y[c + 1024 a]
+        if (c == 0) y_last = load_c_cached(r0, kM * 8, 0);                          // bin M
+    }
+
     for (int row = blockIdx.x; row < batch; row += gridDim.x) {
-        const __amdgpu_buffer_rsrc_t rin =
-            __builtin_amdgcn_make_buffer_rsrc((void *) (X + (size_t) row * (kM + 1)), 0, (kM + 1) * 8, 0x00020000);
+        const int next_row = row + gridDim.x;
+        const __amdgpu_buffer_rsrc_t rnext = __builtin_amdgcn_make_buffer_rsrc(
+            (void *) (X + (size_t) next_row * (kM + 1)), 0, next_row < batch ? (kM + 1) * 8 : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t rout =
             __builtin_amdgcn_make_buffer_rsrc((void *) (x + (size_t) row * 65536), 0, 65536 * 4, 0x00020000);
 
-        // ---- load column c, rows a = 0..31: Y[c + 1024 a]
-        cf v[32];
-        cf y_last = cf{0.f, 0.f};
-        {
-            const int t0 = thread_id(wave_sgpr);
-            const int c = column_of(t0 >> 6, t0 & 63);
-#pragma unroll
-            // default cache policy here: spectrum rows are skewed by 8 B x row, so neighbouring waves
-            // share their boundary lines (nt loads measured 5 % slower on this kernel)
-            for (int a = 0; a < 32; ++a) v[a] = load_c_cached(rin, c * 8, a * 8192);
-            if (c == 0) y_last = load_c_cached(rin, kM * 8, 0);   // bin M
-        }
         inverse_prepass(v, y_last, aux, wave_sgpr);
         three_passes<true>(v, plane, w1024, aux, wave_sgpr, true, false);      // v[p] = z[t + 1024 br5(p)]
-        {
-            const int t4 = thread_id(wave_sgpr);
+
+        // ---- store through the staging area, half a row (16384 complex = 32768 samples) at a time.
+        // Register p holds row br5(p) of column t: even p = rows 0..15 = first half.
+        f2 *stage = (f2 *) plane;
+        const int t4 = thread_id(wave_sgpr);
+        const int c = column_of(t4 >> 6, t4 & 63);
 #pragma unroll
-            for (int p = 0; p < 32; ++p) store_c<0>(v[p], rout, t4 * 8, br5(p) * 8192);       // (nt measured 1 % slower here)
+        for (int p = 0; p < 32; p += 2) stage[t4 + 1024 * br5(p)] = to_f2(v[p]);
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v[2 * a] = load_c_cached(rnext, c * 8, a * 8192);         // even registers are free: next row, rows 0..15
+        lds_barrier();
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int k = 2 * (t4 + 1024 * m);
+            const f2 lo2 = stage[k], hi2 = stage[k + 1];
+            const f4 q = f4{lo2.x, lo2.y, hi2.x, hi2.y};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, q), rout, k * 8, 0, kStream);
+            if (m & 1) __builtin_amdgcn_sched_barrier(0);
         }
+        lds_barrier();
+#pragma unroll
+        for (int p = 1; p < 32; p += 2) stage[t4 + 1024 * (br5(p) - 16)] = to_f2(v[p]);
+#pragma unroll
+        for (int a = 16; a < 32; ++a) v[2 * (a - 16) + 1] = load_c_cached(rnext, c * 8, a * 8192);   // odd registers: rows 16..31
+        y_last = cf{0.f, 0.f};
+        if (c == 0) y_last = load_c_cached(rnext, kM * 8, 0);
+        lds_barrier();
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int k = 2 * (t4 + 1024 * m);
+            const f2 lo2 = stage[k], hi2 = stage[k + 1];
+            const f4 q = f4{lo2.x, lo2.y, hi2.x, hi2.y};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, q), rout, (kM / 2 + k) * 8, 0, kStream);
+            if (m & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        lds_barrier();                                     // plane free for the next row's exchange 1
+        // the next row arrived as (rows 0..15 in even registers, rows 16..31 in odd ones): put it in
+        // natural row order for the pre-pass (a renaming, every index is a constant)
+        cf nxt[32];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) { nxt[a] = v[2 * a]; nxt[16 + a] = v[2 * a + 1]; }
+#pragma unroll
+        for (int a = 0; a < 32; ++a) v[a] = nxt[a];
     }
 }
 
