@@ -470,6 +470,55 @@ __device__ __forceinline__ void inverse_prepass(cf (&v)[32], cf y_last, const f2
     }
 }
 
+// Tail shared by the inverse and the fused kernels: v[p] = z[t + 1024 br5(p)] (time samples of
+// one aligned row) leaves through the LDS staging area, half a row (16384 complex) at a time, as
+// whole lines, 16 B per lane; as soon as a half has left the registers the next row's loads are
+// issued into them (`issue_next(first_half)`), ahead of this row's stores.  Register p holds
+// row br5(p): even p = rows 0..15 = first half.  On return the even registers hold what
+// issue_next(true) loaded, the odd ones what issue_next(false) loaded.
+template<typename IssueNext>
+__device__ __forceinline__ void staged_time_store(cf (&v)[32], float *plane, __amdgpu_buffer_rsrc_t rout, int wave_sgpr,
+                                                  IssueNext issue_next) {
+    f2 *stage = (f2 *) plane;
+    const int t4 = thread_id(wave_sgpr);
+#pragma unroll
+    for (int p = 0; p < 32; p += 2) stage[t4 + 1024 * br5(p)] = to_f2(v[p]);
+    issue_next(true);
+    lds_barrier();
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int k = 2 * (t4 + 1024 * m);
+        const f2 lo2 = stage[k], hi2 = stage[k + 1];
+        const f4 q = f4{lo2.x, lo2.y, hi2.x, hi2.y};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, q), rout, k * 8, 0, kStream);
+        if (m & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    lds_barrier();
+#pragma unroll
+    for (int p = 1; p < 32; p += 2) stage[t4 + 1024 * (br5(p) - 16)] = to_f2(v[p]);
+    issue_next(false);
+    lds_barrier();
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int k = 2 * (t4 + 1024 * m);
+        const f2 lo2 = stage[k], hi2 = stage[k + 1];
+        const f4 q = f4{lo2.x, lo2.y, hi2.x, hi2.y};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, q), rout, (kM / 2 + k) * 8, 0, kStream);
+        if (m & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    lds_barrier();                                         // plane free for the next row's exchange 1
+}
+
+// The pipelined loads land rows 0..15 in the even registers and rows 16..31 in the odd ones:
+// back to natural row order (a renaming, every index is a constant).
+__device__ __forceinline__ void unzip_rows(cf (&v)[32]) {
+    cf nxt[32];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) { nxt[a] = v[2 * a]; nxt[16 + a] = v[2 * a + 1]; }
+#pragma unroll
+    for (int a = 0; a < 32; ++a) v[a] = nxt[a];
+}
+
 // ------------------------------------------------------------------------------------------
 // inverse: X [batch][32769] c32  ->  x [batch][65536] f32        (dsc_irfft, dsc_fft.h:194-236)
 //
@@ -515,48 +564,20 @@ __global__ __launch_bounds__(1024) void irfft64k_kernel(const f2 *__restrict__ X
         inverse_prepass(v, y_last, aux, wave_sgpr);
         three_passes<true>(v, plane, w1024, aux, wave_sgpr, true, false);      // v[p] = z[t + 1024 br5(p)]
 
-        // ---- store through the staging area, half a row (16384 complex = 32768 samples) at a time.
-        // Register p holds row br5(p) of column t: even p = rows 0..15 = first half.
-        f2 *stage = (f2 *) plane;
         const int t4 = thread_id(wave_sgpr);
         const int c = column_of(t4 >> 6, t4 & 63);
+        staged_time_store(v, plane, rout, wave_sgpr, [&](bool first_half) {
+            if (first_half) {
 #pragma unroll
-        for (int p = 0; p < 32; p += 2) stage[t4 + 1024 * br5(p)] = to_f2(v[p]);
+                for (int a = 0; a < 16; ++a) v[2 * a] = load_c_cached(rnext, c * 8, a * 8192);               // rows 0..15
+            } else {
 #pragma unroll
-        for (int a = 0; a < 16; ++a) v[2 * a] = load_c_cached(rnext, c * 8, a * 8192);         // even registers are free: next row, rows 0..15
-        lds_barrier();
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int k = 2 * (t4 + 1024 * m);
-            const f2 lo2 = stage[k], hi2 = stage[k + 1];
-            const f4 q = f4{lo2.x, lo2.y, hi2.x, hi2.y};
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, q), rout, k * 8, 0, kStream);
-            if (m & 1) __builtin_amdgcn_sched_barrier(0);
-        }
-        lds_barrier();
-#pragma unroll
-        for (int p = 1; p < 32; p += 2) stage[t4 + 1024 * (br5(p) - 16)] = to_f2(v[p]);
-#pragma unroll
-        for (int a = 16; a < 32; ++a) v[2 * (a - 16) + 1] = load_c_cached(rnext, c * 8, a * 8192);   // odd registers: rows 16..31
-        y_last = cf{0.f, 0.f};
-        if (c == 0) y_last = load_c_cached(rnext, kM * 8, 0);
-        lds_barrier();
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int k = 2 * (t4 + 1024 * m);
-            const f2 lo2 = stage[k], hi2 = stage[k + 1];
-            const f4 q = f4{lo2.x, lo2.y, hi2.x, hi2.y};
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, q), rout, (kM / 2 + k) * 8, 0, kStream);
-            if (m & 1) __builtin_amdgcn_sched_barrier(0);
-        }
-        lds_barrier();                                     // plane free for the next row's exchange 1
-        // the next row arrived as (rows 0..15 in even registers, rows 16..31 in odd ones): put it in
-        // natural row order for the pre-pass (a renaming, every index is a constant)
-        cf nxt[32];
-#pragma unroll
-        for (int a = 0; a < 16; ++a) { nxt[a] = v[2 * a]; nxt[16 + a] = v[2 * a + 1]; }
-#pragma unroll
-        for (int a = 0; a < 32; ++a) v[a] = nxt[a];
+                for (int a = 16; a < 32; ++a) v[2 * (a - 16) + 1] = load_c_cached(rnext, c * 8, a * 8192);   // rows 16..31
+                y_last = cf{0.f, 0.f};
+                if (c == 0) y_last = load_c_cached(rnext, kM * 8, 0);
+            }
+        });
+        unzip_rows(v);
     }
 }
 
@@ -578,17 +599,21 @@ __global__ __launch_bounds__(1024) void filter64k_kernel(const float *__restrict
     const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void *) H, 0, (kM + 1) * 8, 0x00020000);
     constexpr float kScale = 1.0f / (float) kM;
 
+    cf v[32];                                              // software pipelined like the other two kernels
+    {
+        const int row0 = blockIdx.x;
+        const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(
+            (void *) (x + (size_t) row0 * 65536), 0, row0 < batch ? 65536 * 4 : 0, 0x00020000);
+        const int load_off = thread_id(wave_sgpr) * 8;
+#pragma unroll
+        for (int j1 = 0; j1 < 32; ++j1) v[j1] = load_c(r0, load_off, j1 * 8192);
+    }
     for (int row = blockIdx.x; row < batch; row += gridDim.x) {
-        const __amdgpu_buffer_rsrc_t rin =
-            __builtin_amdgcn_make_buffer_rsrc((void *) (x + (size_t) row * 65536), 0, 65536 * 4, 0x00020000);
+        const int next_row = row + gridDim.x;
+        const __amdgpu_buffer_rsrc_t rnext = __builtin_amdgcn_make_buffer_rsrc(
+            (void *) (x + (size_t) next_row * 65536), 0, next_row < batch ? 65536 * 4 : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t rout =
             __builtin_amdgcn_make_buffer_rsrc((void *) (y + (size_t) row * 65536), 0, 65536 * 4, 0x00020000);
-        cf v[32];
-        {
-            const int load_off = thread_id(wave_sgpr) * 8;
-#pragma unroll
-            for (int j1 = 0; j1 < 32; ++j1) v[j1] = load_c(rin, load_off, j1 * 8192);
-        }
         three_passes<false>(v, plane, w1024, aux, wave_sgpr, false, true);     // v[p] = Z[c + 1024 br5(p)]
 
         // ---- post-pass, multiply by H, pre-pass: all on the pair (k, M-k) held by this lane.
@@ -661,9 +686,19 @@ __global__ __launch_bounds__(1024) void filter64k_kernel(const float *__restrict
         for (int r = 0; r < 32; ++r) z[r] = v[br5(r)];
         three_passes<true>(z, plane, w1024, aux, wave_sgpr, true, false);      // z[p] = y[2(t + 1024 br5(p)) .. +1]
         {
-            const int t4 = thread_id(wave_sgpr);
+            const int load_off = thread_id(wave_sgpr) * 8;
+            staged_time_store(z, plane, rout, wave_sgpr, [&](bool first_half) {
+                if (first_half) {
 #pragma unroll
-            for (int p = 0; p < 32; ++p) store_c<kStream>(z[p], rout, t4 * 8, br5(p) * 8192);
+                    for (int j1 = 0; j1 < 16; ++j1) z[2 * j1] = load_c(rnext, load_off, j1 * 8192);
+                } else {
+#pragma unroll
+                    for (int j1 = 16; j1 < 32; ++j1) z[2 * (j1 - 16) + 1] = load_c(rnext, load_off, j1 * 8192);
+                }
+            });
+            unzip_rows(z);
+#pragma unroll
+            for (int j1 = 0; j1 < 32; ++j1) v[j1] = z[j1];
         }
     }
 }
