@@ -342,7 +342,11 @@ static dsc_tensor *reduce_entry(dsc_ctx *ctx, const dsc_tensor *x, dsc_tensor *o
     long long outer = 1, inner = 1;
     for (int i = 0; i < slot; ++i) outer *= x->shape[i];
     for (int i = slot + 1; i < DSC_MAX_DIMS; ++i) inner *= x->shape[i];
-    dsc_launch_reduce(x->data, out->data, x->dtype, op, outer, x->shape[slot], inner, ctx->stream);
+    // workspace for the segmented path: whatever the scratch arena has, up to 64 MiB
+    ctx->scratch.reset();
+    size_t ws_bytes = ctx->scratch.capacity() > (64u << 20) ? (64u << 20) : ctx->scratch.capacity() / 2;
+    void *ws = ws_bytes >= 4096 ? ctx->scratch.alloc(ws_bytes) : nullptr;
+    dsc_launch_reduce(x->data, out->data, x->dtype, op, outer, x->shape[slot], inner, ws, ws_bytes, ctx->stream);
     return out;
 }
 

@@ -89,4 +89,6 @@ void dsc_launch_binary(const void *a, const void *b, void *out, int dtype, int o
 // ---- reductions along one axis -----------------------------------------------------------
 // x viewed as [outer][axis_n][inner] contiguous; out as [outer][inner].
 // op: 0 sum, 1 mean, 2 max, 3 min
-void dsc_launch_reduce(const void *x, void *out, int dtype, int op, long long outer, int axis_n, long long inner, hipStream_t stream);
+// workspace: scratch for the segmented path (may be NULL)
+void dsc_launch_reduce(const void *x, void *out, int dtype, int op, long long outer, int axis_n, long long inner,
+                       void *workspace, size_t workspace_bytes, hipStream_t stream);

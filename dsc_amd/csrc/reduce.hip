@@ -6,7 +6,9 @@
 //
 //   inner > 1   one thread per output element walks the axis sequentially; neighbouring
 //               threads read neighbouring addresses, so the walk is coalesced AND keeps the
-//               reference's left-to-right accumulation order (sums are bit-identical).
+//               reference's left-to-right accumulation order (sums are bit-identical).  When
+//               that gives too few threads for the chip (few outputs, long axis) the axis is
+//               cut into segments reduced in parallel and combined in segment order.
 //   inner == 1  (reduction over the contiguous last axis) one workgroup per output element:
 //               strided partial accumulators per thread, then a wave shuffle + LDS tree.
 //               Sum order differs from the reference here (tolerance in the tests).
@@ -80,6 +82,48 @@ __global__ void reduce_seq_kernel(const void *x, void *out, long long outer, int
     }
 }
 
+// Same walk, but only rows [seg * seg_len, (seg + 1) * seg_len) of the axis, partial result
+// (value + position along the axis, for the tie rules) to a workspace: used when there are too
+// few outputs to fill the chip (e.g. axis 0 of [4096, 32769]).  Segments are combined in order
+// by reduce_combine_kernel, so the result does not depend on scheduling.
+template<typename R, bool CPLX, int OP>
+__global__ void reduce_seg_kernel(const void *x, R *part_r, R *part_i, int *part_idx, long long outer, int axis_n,
+                                  long long inner, int seg_len) {
+    const long long n_out = outer * inner;
+    const int seg = blockIdx.y;
+    const int j0 = seg * seg_len, j1 = j0 + seg_len < axis_n ? j0 + seg_len : axis_n;
+    for (long long o = (long long) blockIdx.x * blockDim.x + threadIdx.x; o < n_out; o += (long long) gridDim.x * blockDim.x) {
+        const long long oo = o / inner, ii = o - oo * inner;
+        const long long base = oo * axis_n * inner + ii;
+        acc_t<R, CPLX> acc = acc_init<R, CPLX, OP>();
+#pragma unroll 4
+        for (int j = j0; j < j1; ++j) {
+            const acc_t<R, CPLX> v = load_elem<R, CPLX>(x, base + (long long) j * inner, j);
+            if (OP <= 1) { acc.r = acc.r + v.r; acc.i = acc.i + v.i; }
+            else acc = combine<R, CPLX, OP>(acc, v);
+        }
+        const long long at = (long long) seg * n_out + o;
+        part_r[at] = acc.r;
+        if (CPLX) part_i[at] = acc.i;
+        if (OP >= 2) part_idx[at] = acc.idx;
+    }
+}
+
+template<typename R, bool CPLX, int OP>
+__global__ void reduce_combine_kernel(const R *part_r, const R *part_i, const int *part_idx, void *out, long long n_out,
+                                      int n_seg, int axis_n) {
+    for (long long o = (long long) blockIdx.x * blockDim.x + threadIdx.x; o < n_out; o += (long long) gridDim.x * blockDim.x) {
+        acc_t<R, CPLX> acc = acc_init<R, CPLX, OP>();
+        for (int s = 0; s < n_seg; ++s) {
+            const long long at = (long long) s * n_out + o;
+            acc_t<R, CPLX> v = {part_r[at], CPLX ? part_i[at] : (R) 0, OP >= 2 ? part_idx[at] : 0};
+            if (OP <= 1) { acc.r = acc.r + v.r; acc.i = acc.i + v.i; }
+            else acc = combine<R, CPLX, OP>(acc, v);
+        }
+        store_elem<R, CPLX, OP>(out, o, acc, axis_n);
+    }
+}
+
 template<typename R, bool CPLX>
 __device__ __forceinline__ acc_t<R, CPLX> shfl_down_acc(acc_t<R, CPLX> a, int delta) {
     acc_t<R, CPLX> b;
@@ -110,7 +154,28 @@ __global__ __launch_bounds__(256) void reduce_row_kernel(const void *x, void *ou
 }
 
 template<typename R, bool CPLX, int OP>
-void launch_op(const void *x, void *out, long long outer, int axis_n, long long inner, hipStream_t s) {
+void launch_op(const void *x, void *out, long long outer, int axis_n, long long inner, void *ws, size_t ws_bytes, hipStream_t s) {
+    const long long n_out_all = outer * inner;
+    // too few outputs for one thread each to fill the chip, long axis: split the axis
+    if (!(inner == 1 && axis_n >= 64) && n_out_all < 256 * 1024 && axis_n >= 128 && ws != nullptr) {
+        long long n_seg = (512 * 1024 + n_out_all - 1) / n_out_all;
+        if (n_seg > axis_n / 32) n_seg = axis_n / 32;
+        const size_t per = (size_t) n_out_all * (2 * sizeof(R) + sizeof(int));
+        if (n_seg * per > ws_bytes) n_seg = (long long) (ws_bytes / per);
+        if (n_seg >= 2) {
+            const int seg_len = (int) ((axis_n + n_seg - 1) / n_seg);
+            n_seg = (axis_n + seg_len - 1) / seg_len;
+            R *pr = (R *) ws;
+            R *pi = pr + n_seg * n_out_all;
+            int *pidx = (int *) (pi + n_seg * n_out_all);
+            const unsigned bx = (unsigned) ((n_out_all + 255) / 256);
+            hipLaunchKernelGGL((reduce_seg_kernel<R, CPLX, OP>), dim3(bx, (unsigned) n_seg), dim3(256), 0, s, x, pr, pi, pidx, outer,
+                               axis_n, inner, seg_len);
+            hipLaunchKernelGGL((reduce_combine_kernel<R, CPLX, OP>), dim3(bx), dim3(256), 0, s, pr, pi, pidx, out, n_out_all,
+                               (int) n_seg, axis_n);
+            return;
+        }
+    }
     if (inner == 1 && axis_n >= 64) {
         long long blocks = outer < 256 * 16 ? outer : 256 * 16;
         hipLaunchKernelGGL((reduce_row_kernel<R, CPLX, OP>), dim3((unsigned) blocks), dim3(256), 0, s, x, out, outer, axis_n);
@@ -123,23 +188,24 @@ void launch_op(const void *x, void *out, long long outer, int axis_n, long long 
 }
 
 template<typename R, bool CPLX>
-void launch_typed(const void *x, void *out, int op, long long outer, int axis_n, long long inner, hipStream_t s) {
+void launch_typed(const void *x, void *out, int op, long long outer, int axis_n, long long inner, void *ws, size_t wsb, hipStream_t s) {
     switch (op) {
-        case 0: launch_op<R, CPLX, 0>(x, out, outer, axis_n, inner, s); break;
-        case 1: launch_op<R, CPLX, 1>(x, out, outer, axis_n, inner, s); break;
-        case 2: launch_op<R, CPLX, 2>(x, out, outer, axis_n, inner, s); break;
-        default: launch_op<R, CPLX, 3>(x, out, outer, axis_n, inner, s); break;
+        case 0: launch_op<R, CPLX, 0>(x, out, outer, axis_n, inner, ws, wsb, s); break;
+        case 1: launch_op<R, CPLX, 1>(x, out, outer, axis_n, inner, ws, wsb, s); break;
+        case 2: launch_op<R, CPLX, 2>(x, out, outer, axis_n, inner, ws, wsb, s); break;
+        default: launch_op<R, CPLX, 3>(x, out, outer, axis_n, inner, ws, wsb, s); break;
     }
 }
 
 }  // namespace
 
-void dsc_launch_reduce(const void *x, void *out, int dtype, int op, long long outer, int axis_n, long long inner, hipStream_t stream) {
+void dsc_launch_reduce(const void *x, void *out, int dtype, int op, long long outer, int axis_n, long long inner,
+                       void *workspace, size_t workspace_bytes, hipStream_t stream) {
     if (outer * inner <= 0) return;
     switch (dtype) {
-        case 0: launch_typed<float, false>(x, out, op, outer, axis_n, inner, stream); break;
-        case 1: launch_typed<double, false>(x, out, op, outer, axis_n, inner, stream); break;
-        case 2: launch_typed<float, true>(x, out, op, outer, axis_n, inner, stream); break;
-        default: launch_typed<double, true>(x, out, op, outer, axis_n, inner, stream); break;
+        case 0: launch_typed<float, false>(x, out, op, outer, axis_n, inner, workspace, workspace_bytes, stream); break;
+        case 1: launch_typed<double, false>(x, out, op, outer, axis_n, inner, workspace, workspace_bytes, stream); break;
+        case 2: launch_typed<float, true>(x, out, op, outer, axis_n, inner, workspace, workspace_bytes, stream); break;
+        default: launch_typed<double, true>(x, out, op, outer, axis_n, inner, workspace, workspace_bytes, stream); break;
     }
 }

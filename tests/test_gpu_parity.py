@@ -192,3 +192,23 @@ def test_errors_abort_like_the_reference():
         r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True)
         assert r.returncode != 0 and 'SURVIVED' not in r.stdout, (name, r.stdout, r.stderr)
         assert 'RFFT input must be real' in r.stderr or 'IRFFT input must be complex' in r.stderr or 'DSC_ASSERT' in r.stderr, name
+
+
+def test_reduce_segmented_axis(dsc):
+    """Few outputs, long axis (e.g. the mean spectrum over a batch): the axis is cut into segments
+    reduced in parallel.  Sums within tolerance, max/min exact including the tie rules."""
+    from oracle import port
+    rng = np.random.default_rng(12)
+    for dt in (np.complex64, np.float32, np.float64):
+        x = rng.standard_normal((3000, 700)).astype(dt)
+        if np.dtype(dt).kind == 'c':
+            x = (x + 1j * rng.standard_normal(x.shape)).astype(dt)
+        for name, op in (('sum', port.SUM), ('mean', port.MEAN)):
+            got = getattr(dsc, name)(dsc.from_numpy(x), axis=0).numpy()
+            want = port.reduce(x, op, 0, True)
+            tol = 2e-5 if dt != np.float64 else 1e-12
+            assert np.max(np.abs(got - want)) <= tol * np.max(np.abs(x)) * np.sqrt(x.shape[0]), (name, dt)
+        xq = (np.round(x.real * 2) / 2 + (1j * x.imag if np.dtype(dt).kind == 'c' else 0)).astype(dt)
+        for name, op in (('max', port.MAX), ('min', port.MIN)):
+            got = getattr(dsc, name)(dsc.from_numpy(xq), axis=0, keepdims=False).numpy()
+            assert np.array_equal(got, port.reduce(xq, op, 0, False)), (name, dt)
