@@ -102,6 +102,7 @@ def main():
     ap.add_argument('--no-allgather', action='store_true')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (gloo for the CPU dry run)')
     ap.add_argument('--dry-run', action='store_true', help='exercise the multi-process plumbing without a GPU (tests)')
+    ap.add_argument('--share-device', action='store_true', help='testing aid: every rank uses device 0 (rehearse N > 1 on a one-GPU box; use with --backend gloo)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -118,6 +119,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if args.share_device:
+            local_rank = 0
         if not args.dry_run:
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
@@ -179,7 +182,7 @@ def main():
         elapsed = float(t.item())
 
     # ---- all-gather of the output shards over xGMI: its own phase, never part of `value`
-    if dist is not None and not args.dry_run and not args.no_allgather:
+    if dist is not None and not args.dry_run and not args.no_allgather and args.backend == 'nccl':
         try:
             chunk_rows = 1024
             bins = N_FFT // 2 + 1

@@ -143,3 +143,28 @@ def test_full_size_properties(dsc):
     lhs = dsc.rfft(dsc.from_numpy(2 * a + r)).numpy()
     rhs = 2 * Xh[:512] + dsc.rfft(dsc.from_numpy(r)).numpy()
     assert rel_l2(lhs, rhs) <= 2e-6
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N > 1 flow with real device work: two ranks launched as the driver launches them,
+    sharing the box's single GPU (gloo for the barrier / max-reduce; RCCL needs distinct devices)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2',
+           '--batch', '1024', '--backend', 'gloo', '--share-device']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['config']['global_batch'] == 2048 and j['config']['kernel_path'] == 'r2c_64k_regs'
+    assert j['parity']['rel_l2_vs_cpu_oracle'] <= 1e-5
+    assert j['roofline']['achieved'] > 0 and 'cpu_baseline' not in j
