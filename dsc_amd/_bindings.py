@@ -75,6 +75,9 @@ dsc_wrap_c32 = _sig('dsc_wrap_c32', _DscTensor_p, _DscCtx, _C32)
 dsc_wrap_c64 = _sig('dsc_wrap_c64', _DscTensor_p, _DscCtx, _C64)
 dsc_cast = _sig('dsc_cast', _DscTensor_p, _DscCtx, _DscTensor_p, c_uint8)
 dsc_mul = _sig('dsc_mul', _DscTensor_p, _DscCtx, _DscTensor_p, _DscTensor_p, _DscTensor_p)
+dsc_add = _sig('dsc_add', _DscTensor_p, _DscCtx, _DscTensor_p, _DscTensor_p, _DscTensor_p)
+dsc_sub = _sig('dsc_sub', _DscTensor_p, _DscCtx, _DscTensor_p, _DscTensor_p, _DscTensor_p)
+dsc_div = _sig('dsc_div', _DscTensor_p, _DscCtx, _DscTensor_p, _DscTensor_p, _DscTensor_p)
 dsc_sum = _sig('dsc_sum', _DscTensor_p, _DscCtx, _DscTensor_p, _DscTensor_p, c_int, c_bool)
 dsc_mean = _sig('dsc_mean', _DscTensor_p, _DscCtx, _DscTensor_p, _DscTensor_p, c_int, c_bool)
 dsc_max = _sig('dsc_max', _DscTensor_p, _DscCtx, _DscTensor_p, _DscTensor_p, c_int, c_bool)

@@ -306,6 +306,10 @@ static dsc_tensor *binary_entry(dsc_ctx *ctx, dsc_tensor *xa, dsc_tensor *xb, ds
 extern "C" dsc_tensor *dsc_mul(dsc_ctx *ctx, dsc_tensor *xa, dsc_tensor *xb, dsc_tensor *out) {
     return binary_entry(ctx, xa, xb, out, 2);
 }
+// dsc.cpp:1247-1271, 1286-1297: the same skeleton with the other functors
+extern "C" dsc_tensor *dsc_add(dsc_ctx *ctx, dsc_tensor *xa, dsc_tensor *xb, dsc_tensor *out) { return binary_entry(ctx, xa, xb, out, 0); }
+extern "C" dsc_tensor *dsc_sub(dsc_ctx *ctx, dsc_tensor *xa, dsc_tensor *xb, dsc_tensor *out) { return binary_entry(ctx, xa, xb, out, 1); }
+extern "C" dsc_tensor *dsc_div(dsc_ctx *ctx, dsc_tensor *xa, dsc_tensor *xb, dsc_tensor *out) { return binary_entry(ctx, xa, xb, out, 3); }
 
 // ------------------------------------------------------------------------------ reductions
 

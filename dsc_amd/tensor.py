@@ -67,6 +67,24 @@ class Tensor:
     def __rmul__(self, other):
         return mul(other, self)
 
+    def __add__(self, other):
+        return add(self, other)
+
+    def __radd__(self, other):
+        return add(other, self)
+
+    def __sub__(self, other):
+        return sub(self, other)
+
+    def __rsub__(self, other):
+        return sub(other, self)
+
+    def __truediv__(self, other):
+        return true_div(self, other)
+
+    def __rtruediv__(self, other):
+        return true_div(other, self)
+
     def numpy(self) -> np.ndarray:
         """Device -> host copy (the reference returns a zero-copy view, tensor.py:305-323)."""
         out = np.empty(self._shape if self._n_dim > 0 else (1,), dtype=DTYPE_TO_NP[self._dtype])
@@ -142,9 +160,25 @@ def _wrap_operands(xa, xb) -> Tuple[Tensor, Tensor]:
     return _wrap(xa, wrap_dtype), _wrap(xb, wrap_dtype)
 
 
-def mul(xa, xb, out: Union[Tensor, None] = None) -> Tensor:
+def _binary(f, xa, xb, out) -> Tensor:
     xa, xb = _wrap_operands(xa, xb)
-    return Tensor(B.dsc_mul(_get_ctx(), xa._c_ptr, xb._c_ptr, _c_ptr_or_none(out)), out is not None)
+    return Tensor(f(_get_ctx(), xa._c_ptr, xb._c_ptr, _c_ptr_or_none(out)), out is not None)
+
+
+def mul(xa, xb, out: Union[Tensor, None] = None) -> Tensor:
+    return _binary(B.dsc_mul, xa, xb, out)
+
+
+def add(xa, xb, out: Union[Tensor, None] = None) -> Tensor:         # python/dsc/tensor.py:461-467
+    return _binary(B.dsc_add, xa, xb, out)
+
+
+def sub(xa, xb, out: Union[Tensor, None] = None) -> Tensor:         # :469-475
+    return _binary(B.dsc_sub, xa, xb, out)
+
+
+def true_div(xa, xb, out: Union[Tensor, None] = None) -> Tensor:    # :485-491
+    return _binary(B.dsc_div, xa, xb, out)
 
 
 def _reduce(f, x: Tensor, out, axis: int, keepdims: bool) -> Tensor:

@@ -113,6 +113,11 @@ dsc_tensor *dsc_cast(dsc_ctx *ctx, dsc_tensor *x, dsc_dtype new_dtype);
  * NumPy-style broadcasting over the 4 right-aligned dims, result dtype from the
  * promotion table dsc_dtype.h:73-78 (F64 x C32 -> C32).  out may be NULL. */
 dsc_tensor *dsc_mul(dsc_ctx *ctx, dsc_tensor *xa, dsc_tensor *xb, dsc_tensor *out);
+/* dsc.h:265-283, dsc.cpp:1247-1297 — same skeleton with add_op / sub_op / div_op (dsc_ops.h:46-90);
+ * SURVEY 8f "next" row 2. */
+dsc_tensor *dsc_add(dsc_ctx *ctx, dsc_tensor *xa, dsc_tensor *xb, dsc_tensor *out);
+dsc_tensor *dsc_sub(dsc_ctx *ctx, dsc_tensor *xa, dsc_tensor *xb, dsc_tensor *out);
+dsc_tensor *dsc_div(dsc_ctx *ctx, dsc_tensor *xa, dsc_tensor *xb, dsc_tensor *out);
 
 /* dsc.h:358-380, dsc.cpp:1771-1953.  Sequential left-to-right accumulation order per
  * output element is NOT reproduced on the GPU (tree order); max/min are exact

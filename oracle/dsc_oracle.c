@@ -270,7 +270,10 @@ static size_t orc_bcast_index(const orc_tensor *x, const int *out_shape, const i
     return off;
 }
 
-#define ORC_MUL_BODY(R)                                                                         \
+/* One loop per functor (as the reference instantiates binary_op<T, Op> per Op, dsc.cpp:1186-1245):
+ * CPLX_RE / CPLX_IM / REAL are the expressions of dsc_ops.h:46-90 in terms of ar, ai, br, bi / va, vb. */
+#define ORC_BINARY_LOOP(R, CPLX_RE, CPLX_IM, REAL)                                              \
+    {                                                                                           \
     const R *a = (const R *) ca.data, *b = (const R *) cb.data;                                 \
     R *o = (R *) out->data;                                                                     \
     const int a_scalar = xa->n_dim == 1 && xa->shape[ORC_MAX_DIMS - 1] == 1;                    \
@@ -283,21 +286,32 @@ static size_t orc_bcast_index(const orc_tensor *x, const int *out_shape, const i
         else { ia = orc_bcast_index(&ca, out->shape, idx); ib = orc_bcast_index(&cb, out->shape, idx); } \
         if (cplx) {                                                                             \
             const R ar = a[2 * ia], ai = a[2 * ia + 1], br = b[2 * ib], bi = b[2 * ib + 1];     \
-            o[2 * i]     = (ar * br) - (ai * bi);                                               \
-            o[2 * i + 1] = (ar * bi) + (ai * br);                                               \
+            o[2 * i]     = CPLX_RE;                                                             \
+            o[2 * i + 1] = CPLX_IM;                                                             \
         } else {                                                                                \
-            o[i] = a[ia] * b[ib];                                                               \
+            const R va = a[ia], vb = b[ib];                                                     \
+            o[i] = REAL;                                                                        \
         }                                                                                       \
         for (int d = ORC_MAX_DIMS - 1; d >= 0; --d) {                                           \
             if (++idx[d] < out->shape[d]) break;                                                \
             idx[d] = 0;                                                                         \
         }                                                                                       \
+    }                                                                                           \
     }
 
-/* dsc/src/dsc.cpp:1273-1284 via :44-69 and :1186-1245; product per
- * dsc/include/dsc_ops.h:68-78.  Operands are first cast to the promoted dtype
+#define ORC_BINARY_BODY(R)                                                                                        \
+    switch (op) {                                                                                                 \
+        case ORC_ADD: ORC_BINARY_LOOP(R, ar + br, ai + bi, va + vb) break;                                        \
+        case ORC_SUB: ORC_BINARY_LOOP(R, ar - br, ai - bi, va - vb) break;                                        \
+        case ORC_MUL: ORC_BINARY_LOOP(R, (ar * br) - (ai * bi), (ar * bi) + (ai * br), va * vb) break;            \
+        default:      ORC_BINARY_LOOP(R, ((ar * br) + (ai * bi)) / ((br * br) + (bi * bi)),                       \
+                                      ((ai * br) - (ar * bi)) / ((br * br) + (bi * bi)), va / vb) break;          \
+    }
+
+/* dsc_add / dsc_sub / dsc_mul / dsc_div: dsc/src/dsc.cpp:1247-1297 via :44-69 and :1186-1245;
+ * functors per dsc/include/dsc_ops.h:46-90.  Operands are first cast to the promoted dtype
  * (the reference does it in its scratch arena, :65-68). */
-int orc_mul(const orc_tensor *xa, const orc_tensor *xb, orc_tensor *out) {
+int orc_binary(const orc_tensor *xa, const orc_tensor *xb, orc_tensor *out, int op) {
     int shape[4], n_dim, dtype;
     if (orc_mul_out_shape(xa, xb, shape, &n_dim, &dtype)) return -1;
     if (out->dtype != dtype || memcmp(shape, out->shape, sizeof(shape))) return -1;
@@ -315,12 +329,14 @@ int orc_mul(const orc_tensor *xa, const orc_tensor *xb, orc_tensor *out) {
         orc_cast(xb, &cb);
     }
     const int cplx = dtype == ORC_C32 || dtype == ORC_C64;
-    if (dtype == ORC_F32 || dtype == ORC_C32) { ORC_MUL_BODY(float) }
-    else                                      { ORC_MUL_BODY(double) }
+    if (dtype == ORC_F32 || dtype == ORC_C32) { ORC_BINARY_BODY(float) }
+    else                                      { ORC_BINARY_BODY(double) }
     free(tmp_a);
     free(tmp_b);
     return 0;
 }
+
+int orc_mul(const orc_tensor *xa, const orc_tensor *xb, orc_tensor *out) { return orc_binary(xa, xb, out, ORC_MUL); }
 
 /* ------------------------------------------------------------------ reductions */
 

@@ -84,6 +84,9 @@ void orc_cast(const orc_tensor *x, orc_tensor *out);
  * out shape = element-wise max of the operand shapes, dtype = orc_promote. */
 int orc_mul_out_shape(const orc_tensor *xa, const orc_tensor *xb, int out_shape[4], int *out_n_dim, int *out_dtype);
 int orc_mul(const orc_tensor *xa, const orc_tensor *xb, orc_tensor *out);
+/* dsc_add / dsc_sub / dsc_mul / dsc_div (dsc.cpp:1247-1297; dsc_ops.h:46-90): same shape and promotion rules. */
+enum { ORC_ADD = 0, ORC_SUB = 1, ORC_MUL = 2, ORC_DIV = 3 };
+int orc_binary(const orc_tensor *xa, const orc_tensor *xb, orc_tensor *out, int op);
 
 /* Reductions (dsc.cpp:83-115, 1774-1953; dsc_ops.h:46-55, 318-339).
  * op: 0 sum, 1 mean, 2 max, 3 min. */

@@ -48,6 +48,7 @@ def lib():
             getattr(_lib, name).argtypes = [P, P, c_int, c_int]
         _lib.orc_mul_out_shape.argtypes = [P, P, I4, I4, I4]
         _lib.orc_mul.argtypes = [P, P, P]
+        _lib.orc_binary.argtypes = [P, P, P, c_int]
         _lib.orc_reduce_out_shape.argtypes = [P, c_int, c_int, I4, I4]
         _lib.orc_reduce.argtypes = [P, P, c_int, c_int]
         _lib.orc_cast.argtypes = [P, P]
@@ -104,6 +105,21 @@ def rfft(x, n=-1, axis=-1):
 
 def irfft(x, n=-1, axis=-1):
     return _fft_like('orc_irfft', x, n, axis, rfft_forward=False)
+
+
+ADD, SUB, MUL, DIV = 0, 1, 2, 3
+
+
+def binary(a, b, op):
+    ta, a = _wrap(a)
+    tb, b = _wrap(b)
+    shape = (c_int * 4)()
+    nd, dt = c_int(), c_int()
+    if lib().orc_mul_out_shape(ctypes.byref(ta), ctypes.byref(tb), shape, ctypes.byref(nd), ctypes.byref(dt)):
+        raise ValueError('binary: shapes do not broadcast')
+    to, out = _alloc(list(shape), nd.value, dt.value)
+    assert lib().orc_binary(ctypes.byref(ta), ctypes.byref(tb), ctypes.byref(to), op) == 0
+    return out
 
 
 def mul(a, b):

@@ -65,8 +65,10 @@ class Ref:
             f = getattr(L, name)
             f.argtypes = [c_void_p, TP, TP, c_int, c_int]
             f.restype = TP
-        L.dsc_mul.argtypes = [c_void_p, TP, TP, TP]
-        L.dsc_mul.restype = TP
+        for name in ('dsc_add', 'dsc_sub', 'dsc_mul', 'dsc_div'):
+            f = getattr(L, name)
+            f.argtypes = [c_void_p, TP, TP, TP]
+            f.restype = TP
         for name in ('dsc_sum', 'dsc_mean', 'dsc_max', 'dsc_min'):
             f = getattr(L, name)
             f.argtypes = [c_void_p, TP, TP, c_int, c_bool]
@@ -119,6 +121,13 @@ class Ref:
     def mul(self, a, b):
         ta, tb = self.put(a), self.put(b)
         out = self.take(self.L.dsc_mul(self.ctx, ta, tb, None))
+        self.free(ta, tb)
+        return out
+
+    def binary(self, a, b, op):
+        ta, tb = self.put(a), self.put(b)
+        f = getattr(self.L, 'dsc_' + ('add', 'sub', 'mul', 'div')[op])
+        out = self.take(f(self.ctx, ta, tb, None))
         self.free(ta, tb)
         return out
 

@@ -146,6 +146,14 @@ def main():
         else:
             add('filter', 'filter', (s, b), y, n=n)
 
+    # ---- add / sub / div: same skeleton as mul; appended last so that the
+    # random stream of the groups above is unchanged
+    for op, name in ((0, 'add'), (1, 'sub'), (3, 'div')):
+        for da, db in (('c32', 'c32'), ('f32', 'f32'), ('f64', 'c32'), ('c64', 'f32')):
+            for sa, sb in (((6, 33), (6, 33)), ((6, 33), (33,)), ((6, 33), (1,)), ((1,), (6, 33)), ((3, 1, 5), (1, 4, 1))):
+                a, b = rnd(rng, sa, NP[da]), rnd(rng, sb, NP[db])
+                add('binary', name, (a, b), R.binary(a, b, op))
+
     for group, g in arrays.items():
         np.savez_compressed(os.path.join(HERE, f'{group}.npz'), **g)
         print(group, len(g), 'arrays', os.path.getsize(os.path.join(HERE, f'{group}.npz')) // 1024, 'KiB')

@@ -48,6 +48,17 @@ def test_golden_mul(dsc, golden):
         assert_close(got, y, what=rec['key'])
 
 
+def test_golden_add_sub_div(dsc, golden):
+    f = {'add': dsc.add, 'sub': dsc.sub, 'div': dsc.true_div}
+    for rec, xs, y in golden.cases('binary'):
+        got = f[rec['op']](dsc.from_numpy(xs[0]), dsc.from_numpy(xs[1])).numpy()
+        assert_close(got, y, what=rec['key'])
+    a = dsc.from_numpy(np.arange(6, dtype=np.float32).reshape(2, 3))
+    assert np.array_equal((a + 1).numpy(), np.arange(6, dtype=np.float32).reshape(2, 3) + 1)
+    assert np.array_equal((1 - a).numpy(), 1 - np.arange(6, dtype=np.float32).reshape(2, 3))
+    assert np.allclose((a / 2).numpy(), np.arange(6, dtype=np.float32).reshape(2, 3) / 2)
+
+
 def test_golden_reductions(dsc, golden):
     for rec, xs, y in golden.cases('reduce'):
         got = getattr(dsc, rec['op'])(dsc.from_numpy(xs[0]), axis=rec['axis'], keepdims=rec['keepdims']).numpy()

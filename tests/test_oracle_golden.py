@@ -98,3 +98,13 @@ def test_semantics_quirks():
     with pytest.raises(ValueError):
         port.irfft(x)         # real input: the reference aborts
     assert port.mul(np.ones(3, np.float64), np.ones(3, np.complex64)).dtype == np.complex64
+
+
+def test_add_sub_div(golden):
+    ops = {'add': port.ADD, 'sub': port.SUB, 'div': port.DIV}
+    n = 0
+    for rec, xs, y in golden.cases('binary'):
+        got = port.binary(xs[0], xs[1], ops[rec['op']])
+        _check(got, y, f"{rec['key']} {xs[0].dtype}{xs[0].shape} {rec['op']} {xs[1].dtype}{xs[1].shape}")
+        n += 1
+    assert n == 60

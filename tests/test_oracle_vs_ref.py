@@ -65,6 +65,8 @@ def test_mul_reduce_cast():
             for sa, sb in (((4, 5), (4, 5)), ((4, 5), (5,)), ((4, 5), (1,)), ((1,), (4, 5)), ((3, 1, 5), (1, 4, 1))):
                 a, b = rnd(rng, sa, da), rnd(rng, sb, db)
                 same(port.mul(a, b), R.mul(a, b), np.result_type(da))
+                for op in (port.ADD, port.SUB, port.DIV):
+                    same(port.binary(a, b, op), R.binary(a, b, op), np.result_type(da))
             x = rnd(rng, (3, 4), da)
             assert np.array_equal(port.cast(x, db), R.cast(x, db))
     for dt in DTS:
