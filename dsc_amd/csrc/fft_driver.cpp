@@ -14,6 +14,7 @@
 #include "kernels.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -178,6 +179,19 @@ static void run_four_step(dsc_ctx *ctx, const fft_job &j, bool sp, const dsc_fft
     long long chunk = (long long) ((ctx->scratch.capacity() - 2 * DSC_DEVICE_ALIGN) / (2 * line_bytes));
     if (chunk < 1)
         DSC_LOG_FATAL("scratch arena too small: a %d-point transform needs %.1f MB of scratch", L, 2.0 * line_bytes / 1048576.);
+    // Keep a chunk's working set (input rows + two work buffers + output rows) inside the 256 MiB
+    // Infinity Cache, so that the intermediate of the column pass is still on-die when the row pass
+    // reads it: ~4 line-sized buffers per row.
+    {
+        static long long cap_bytes = -1;
+        if (cap_bytes < 0) {
+            const char *e = getenv("DSC_4STEP_CHUNK_MB");
+            cap_bytes = (e ? atoll(e) : 192) << 20;
+        }
+        long long by_cache = cap_bytes / (long long) (4 * line_bytes);
+        if (by_cache < 1) by_cache = 1;
+        if (chunk > by_cache) chunk = by_cache;
+    }
     if (chunk > n_lines) chunk = n_lines;
     char *A = ctx->scratch.alloc((size_t) chunk * line_bytes);
     char *B = ctx->scratch.alloc((size_t) chunk * line_bytes);
