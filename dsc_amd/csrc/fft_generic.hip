@@ -21,6 +21,10 @@
 
 #include <hip/hip_runtime.h>
 
+#ifndef DSC_GEN_SKIP
+#define DSC_GEN_SKIP 0          // diagnostic builds (tools/probe_generic.hip): 1 skip stages, 2 skip gather loads, 4 skip scatter stores
+#endif
+
 namespace {
 
 constexpr int kMaxThreads = 1024;           // block size is chosen per launch: 64 .. 1024 threads
@@ -167,6 +171,7 @@ __global__ __launch_bounds__(kMaxThreads) void fft_lines_kernel(const lines_para
         C *t = src; src = dst; dst = t;
     }
 
+    if (!(DSC_GEN_SKIP & 1))
     // ---------------------------------------------------------------- Stockham stages
     // Stage with Ns points already combined per sub-transform and radix R:
     //   v[r]  = src[j + r L/R] * W_{Ns R}^{r k},   k = j mod Ns
