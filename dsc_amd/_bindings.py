@@ -78,6 +78,11 @@ dsc_mul = _sig('dsc_mul', _DscTensor_p, _DscCtx, _DscTensor_p, _DscTensor_p, _Ds
 dsc_add = _sig('dsc_add', _DscTensor_p, _DscCtx, _DscTensor_p, _DscTensor_p, _DscTensor_p)
 dsc_sub = _sig('dsc_sub', _DscTensor_p, _DscCtx, _DscTensor_p, _DscTensor_p, _DscTensor_p)
 dsc_div = _sig('dsc_div', _DscTensor_p, _DscCtx, _DscTensor_p, _DscTensor_p, _DscTensor_p)
+dsc_abs = _sig('dsc_abs', _DscTensor_p, _DscCtx, _DscTensor_p, _DscTensor_p)
+dsc_angle = _sig('dsc_angle', _DscTensor_p, _DscCtx, _DscTensor_p)
+dsc_conj = _sig('dsc_conj', _DscTensor_p, _DscCtx, _DscTensor_p)
+dsc_real = _sig('dsc_real', _DscTensor_p, _DscCtx, _DscTensor_p)
+dsc_imag = _sig('dsc_imag', _DscTensor_p, _DscCtx, _DscTensor_p)
 dsc_sum = _sig('dsc_sum', _DscTensor_p, _DscCtx, _DscTensor_p, _DscTensor_p, c_int, c_bool)
 dsc_mean = _sig('dsc_mean', _DscTensor_p, _DscCtx, _DscTensor_p, _DscTensor_p, c_int, c_bool)
 dsc_max = _sig('dsc_max', _DscTensor_p, _DscCtx, _DscTensor_p, _DscTensor_p, c_int, c_bool)

@@ -311,6 +311,50 @@ extern "C" dsc_tensor *dsc_add(dsc_ctx *ctx, dsc_tensor *xa, dsc_tensor *xb, dsc
 extern "C" dsc_tensor *dsc_sub(dsc_ctx *ctx, dsc_tensor *xa, dsc_tensor *xb, dsc_tensor *out) { return binary_entry(ctx, xa, xb, out, 1); }
 extern "C" dsc_tensor *dsc_div(dsc_ctx *ctx, dsc_tensor *xa, dsc_tensor *xb, dsc_tensor *out) { return binary_entry(ctx, xa, xb, out, 3); }
 
+// ------------------------------------------------------------------------------ unary (spectrum consumers)
+
+static dsc_dtype as_real(dsc_dtype t) { return dsc_is_single(t) ? DSC_F32 : DSC_F64; }
+
+static dsc_tensor *unary_entry(dsc_ctx *ctx, const dsc_tensor *x, dsc_tensor *out, int op, dsc_dtype out_dtype) {
+    if (out == nullptr) {
+        out = dsc_new_tensor(ctx, x->n_dim, &x->shape[DSC_MAX_DIMS - x->n_dim], out_dtype, nullptr);
+    } else {                                          // dsc.cpp:1490-1494
+        DSC_ASSERT(out->dtype == out_dtype);
+        DSC_ASSERT(out->n_dim == x->n_dim);
+        DSC_ASSERT(memcmp(out->shape, x->shape, sizeof(x->shape)) == 0);
+    }
+    dsc_launch_unary(x->data, x->dtype, out->data, op, x->ne, ctx->stream);
+    return out;
+}
+
+// dsc.cpp:1480-1513
+extern "C" dsc_tensor *dsc_abs(dsc_ctx *ctx, const dsc_tensor *x, dsc_tensor *out) {
+    DSC_ASSERT(x != nullptr);
+    return unary_entry(ctx, x, out, 0, as_real(x->dtype));
+}
+// dsc.cpp:1515-1541
+extern "C" dsc_tensor *dsc_angle(dsc_ctx *ctx, const dsc_tensor *x) {
+    DSC_ASSERT(x != nullptr);
+    return unary_entry(ctx, x, nullptr, 1, as_real(x->dtype));
+}
+// dsc.cpp:1543-1568: a real input is returned as is
+extern "C" dsc_tensor *dsc_conj(dsc_ctx *ctx, dsc_tensor *x) {
+    DSC_ASSERT(x != nullptr);
+    if (!dsc_is_complex(x->dtype)) return x;
+    return unary_entry(ctx, x, nullptr, 2, x->dtype);
+}
+// dsc.cpp:1570-1594
+extern "C" dsc_tensor *dsc_real(dsc_ctx *ctx, dsc_tensor *x) {
+    DSC_ASSERT(x != nullptr);
+    if (!dsc_is_complex(x->dtype)) return x;
+    return unary_entry(ctx, x, nullptr, 3, as_real(x->dtype));
+}
+// dsc.cpp:1596-1622
+extern "C" dsc_tensor *dsc_imag(dsc_ctx *ctx, const dsc_tensor *x) {
+    DSC_ASSERT(x != nullptr);
+    return unary_entry(ctx, x, nullptr, 4, as_real(x->dtype));
+}
+
 // ------------------------------------------------------------------------------ reductions
 
 // dsc.cpp:83-115 (validate_reduce_params).  For keep_dims=false the reference leaves

@@ -101,6 +101,43 @@ void binary_typed(const void *a, const void *b, void *out, int op, const dsc_bca
     }
 }
 
+// abs / angle / conj / real / imag: dsc/src/dsc.cpp:1480-1622, functors dsc_ops.h:242-303.
+// OP: 0 abs, 1 angle, 2 conj, 3 real, 4 imag.  Tin real or complex, output real (conj: same as input).
+template<typename Tin, int OP>
+__global__ void unary_kernel(const Tin *in, void *out, long long ne) {
+    using R = typename elem<Tin>::real;
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < ne; i += (long long) gridDim.x * blockDim.x) {
+        R re, im;
+        if constexpr (elem<Tin>::cplx) { const Tin v = in[i]; re = v.x; im = v.y; }
+        else                           { re = in[i]; im = (R) 0; }
+        if constexpr (OP == 0) {
+            if constexpr (elem<Tin>::cplx) ((R *) out)[i] = sqrt((re * re) + (im * im));
+            else                           ((R *) out)[i] = re >= 0 ? re : -re;
+        } else if constexpr (OP == 1) {
+            ((R *) out)[i] = atan2(im, re);
+        } else if constexpr (OP == 2) {
+            if constexpr (elem<Tin>::cplx) ((Tin *) out)[i] = Tin{re, -im};
+            else                           ((R *) out)[i] = re;
+        } else if constexpr (OP == 3) {
+            ((R *) out)[i] = re;
+        } else {
+            ((R *) out)[i] = im;
+        }
+    }
+}
+
+template<typename Tin>
+void unary_typed(const void *in, void *out, int op, long long ne, dim3 grid, hipStream_t s) {
+    const Tin *x = (const Tin *) in;
+    switch (op) {
+        case 0: hipLaunchKernelGGL((unary_kernel<Tin, 0>), grid, dim3(256), 0, s, x, out, ne); break;
+        case 1: hipLaunchKernelGGL((unary_kernel<Tin, 1>), grid, dim3(256), 0, s, x, out, ne); break;
+        case 2: hipLaunchKernelGGL((unary_kernel<Tin, 2>), grid, dim3(256), 0, s, x, out, ne); break;
+        case 3: hipLaunchKernelGGL((unary_kernel<Tin, 3>), grid, dim3(256), 0, s, x, out, ne); break;
+        default: hipLaunchKernelGGL((unary_kernel<Tin, 4>), grid, dim3(256), 0, s, x, out, ne); break;
+    }
+}
+
 inline dim3 stream_grid(long long ne) {
     long long blocks = (ne + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;        // 8 blocks per CU, grid-stride beyond that
@@ -118,6 +155,17 @@ void dsc_launch_cast(const void *in, int in_dtype, void *out, int out_dtype, lon
         case 1: cast_from<double>(in, out, out_dtype, ne, grid, stream); break;
         case 2: cast_from<cx<float>>(in, out, out_dtype, ne, grid, stream); break;
         default: cast_from<cx<double>>(in, out, out_dtype, ne, grid, stream); break;
+    }
+}
+
+void dsc_launch_unary(const void *in, int in_dtype, void *out, int op, long long ne, hipStream_t stream) {
+    if (ne <= 0) return;
+    const dim3 grid = stream_grid(ne);
+    switch (in_dtype) {
+        case 0: unary_typed<float>(in, out, op, ne, grid, stream); break;
+        case 1: unary_typed<double>(in, out, op, ne, grid, stream); break;
+        case 2: unary_typed<cx<float>>(in, out, op, ne, grid, stream); break;
+        default: unary_typed<cx<double>>(in, out, op, ne, grid, stream); break;
     }
 }
 

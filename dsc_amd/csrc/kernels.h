@@ -76,6 +76,9 @@ void   dsc_launch_filter64k(const float *s, const void *H, float *y, int batch, 
 // dtype codes are dsc_dtype values (0 f32, 1 f64, 2 c32, 3 c64)
 void dsc_launch_cast(const void *in, int in_dtype, void *out, int out_dtype, long long ne, hipStream_t stream);
 
+// op: 0 abs, 1 angle, 2 conj, 3 real, 4 imag (output real dtype of the input; conj keeps the dtype)
+void dsc_launch_unary(const void *in, int in_dtype, void *out, int op, long long ne, hipStream_t stream);
+
 struct dsc_bcast_args {
     int out_shape[4];
     int a_stride[4];       // element strides, 0 on broadcast dims (dsc_iter.h:67-95)

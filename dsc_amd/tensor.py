@@ -181,6 +181,32 @@ def true_div(xa, xb, out: Union[Tensor, None] = None) -> Tensor:    # :485-491
     return _binary(B.dsc_div, xa, xb, out)
 
 
+def _same_ptr(a, b) -> bool:
+    return B.ctypes.cast(a, B.c_void_p).value == B.ctypes.cast(b, B.c_void_p).value
+
+
+def absolute(x: Tensor, out: Union[Tensor, None] = None) -> Tensor:       # python/dsc/tensor.py:530-534
+    return Tensor(B.dsc_abs(_get_ctx(), x._c_ptr, _c_ptr_or_none(out)), out is not None)
+
+
+def angle(x: Tensor) -> Tensor:                                           # :537-538
+    return Tensor(B.dsc_angle(_get_ctx(), x._c_ptr))
+
+
+def conj(x: Tensor) -> Tensor:                                            # :541-544 (a real tensor comes back as a view of itself)
+    p = B.dsc_conj(_get_ctx(), x._c_ptr)
+    return Tensor(p, view=_same_ptr(p, x._c_ptr))
+
+
+def real(x: Tensor) -> Tensor:                                            # :547-550
+    p = B.dsc_real(_get_ctx(), x._c_ptr)
+    return Tensor(p, view=_same_ptr(p, x._c_ptr))
+
+
+def imag(x: Tensor) -> Tensor:                                            # :553-554
+    return Tensor(B.dsc_imag(_get_ctx(), x._c_ptr))
+
+
 def _reduce(f, x: Tensor, out, axis: int, keepdims: bool) -> Tensor:
     return Tensor(f(_get_ctx(), x._c_ptr, _c_ptr_or_none(out), axis, keepdims), out is not None)
 

@@ -119,6 +119,15 @@ dsc_tensor *dsc_add(dsc_ctx *ctx, dsc_tensor *xa, dsc_tensor *xb, dsc_tensor *ou
 dsc_tensor *dsc_sub(dsc_ctx *ctx, dsc_tensor *xa, dsc_tensor *xb, dsc_tensor *out);
 dsc_tensor *dsc_div(dsc_ctx *ctx, dsc_tensor *xa, dsc_tensor *xb, dsc_tensor *out);
 
+/* dsc.h:325-340, dsc.cpp:1480-1622 (functors dsc_ops.h:242-303) — magnitude / phase / parts of a spectrum
+ * (SURVEY 8f "next" row 2).  abs, angle, imag (and real of a complex tensor) return the REAL dtype of x;
+ * dsc_conj / dsc_real of a real tensor return x itself, as the reference does. */
+dsc_tensor *dsc_abs(dsc_ctx *ctx, const dsc_tensor *x, dsc_tensor *out);
+dsc_tensor *dsc_angle(dsc_ctx *ctx, const dsc_tensor *x);
+dsc_tensor *dsc_conj(dsc_ctx *ctx, dsc_tensor *x);
+dsc_tensor *dsc_real(dsc_ctx *ctx, dsc_tensor *x);
+dsc_tensor *dsc_imag(dsc_ctx *ctx, const dsc_tensor *x);
+
 /* dsc.h:358-380, dsc.cpp:1771-1953.  Sequential left-to-right accumulation order per
  * output element is NOT reproduced on the GPU (tree order); max/min are exact
  * including the reference's tie rules on the real part (dsc_ops.h:318-339). */

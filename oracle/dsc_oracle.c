@@ -338,6 +338,40 @@ int orc_binary(const orc_tensor *xa, const orc_tensor *xb, orc_tensor *out, int 
 
 int orc_mul(const orc_tensor *xa, const orc_tensor *xb, orc_tensor *out) { return orc_binary(xa, xb, out, ORC_MUL); }
 
+/* ------------------------------------------------------------------ unary (spectrum consumers) */
+
+int orc_unary_out_dtype(int dtype, int op) {
+    if (op == ORC_CONJ) return dtype;
+    return (dtype == ORC_F32 || dtype == ORC_C32) ? ORC_F32 : ORC_F64;     /* as_real, dsc.cpp:1487 */
+}
+
+/* One loop per functor and precision, as the reference instantiates complex_unary<Tin, Tout>(x, out, op). */
+#define ORC_UNARY_BODY(R, SQRT, ATAN2)                                                          \
+    {                                                                                           \
+    const R *xd = (const R *) x->data;                                                          \
+    R *od = (R *) out->data;                                                                    \
+    for (int i = 0; i < x->ne; ++i) {                                                           \
+        const R re = cplx ? xd[2 * i] : xd[i];                                                  \
+        const R im = cplx ? xd[2 * i + 1] : (R) 0;                                              \
+        switch (op) {                                                                           \
+            case ORC_ABS:      od[i] = cplx ? SQRT((re * re) + (im * im)) : (re >= 0 ? re : -re); break;   /* dsc_ops.h:273-286 */ \
+            case ORC_ANGLE:    od[i] = cplx ? ATAN2(im, re) : ATAN2((R) 0, re); break;                       /* dsc_ops.h:288-303 */ \
+            case ORC_CONJ:     if (cplx) { od[2 * i] = re; od[2 * i + 1] = -im; } else od[i] = re; break;     /* dsc_ops.h:242-249 */ \
+            case ORC_REALPART: od[i] = re; break;                                                             /* dsc_ops.h:251-258 */ \
+            default:           od[i] = im; break;                                                             /* dsc_ops.h:260-271 */ \
+        }                                                                                       \
+    }                                                                                           \
+    }
+
+/* dsc/src/dsc.cpp:1480-1622 */
+int orc_unary(const orc_tensor *x, orc_tensor *out, int op) {
+    if (out->dtype != orc_unary_out_dtype(x->dtype, op) || out->ne != x->ne) return -1;
+    const int cplx = x->dtype == ORC_C32 || x->dtype == ORC_C64;
+    if (x->dtype == ORC_F32 || x->dtype == ORC_C32) ORC_UNARY_BODY(float, sqrtf, atan2f)
+    else                                            ORC_UNARY_BODY(double, sqrt, atan2)
+    return 0;
+}
+
 /* ------------------------------------------------------------------ reductions */
 
 /* dsc/src/dsc.cpp:83-115.  (The reference fills the leading slots of the

@@ -88,6 +88,13 @@ int orc_mul(const orc_tensor *xa, const orc_tensor *xb, orc_tensor *out);
 enum { ORC_ADD = 0, ORC_SUB = 1, ORC_MUL = 2, ORC_DIV = 3 };
 int orc_binary(const orc_tensor *xa, const orc_tensor *xb, orc_tensor *out, int op);
 
+/* dsc_abs / dsc_angle / dsc_conj / dsc_real / dsc_imag (dsc.cpp:1480-1622; dsc_ops.h:242-303) — SURVEY 8f row 2.
+ * abs, angle, real, imag produce the REAL dtype of x; conj keeps it.  (dsc_conj / dsc_real of a real tensor
+ * return x itself in the reference; here out simply receives a copy.) */
+enum { ORC_ABS = 0, ORC_ANGLE = 1, ORC_CONJ = 2, ORC_REALPART = 3, ORC_IMAGPART = 4 };
+int orc_unary_out_dtype(int dtype, int op);
+int orc_unary(const orc_tensor *x, orc_tensor *out, int op);
+
 /* Reductions (dsc.cpp:83-115, 1774-1953; dsc_ops.h:46-55, 318-339).
  * op: 0 sum, 1 mean, 2 max, 3 min. */
 enum { ORC_SUM = 0, ORC_MEAN = 1, ORC_MAX = 2, ORC_MIN = 3 };

@@ -49,6 +49,8 @@ def lib():
         _lib.orc_mul_out_shape.argtypes = [P, P, I4, I4, I4]
         _lib.orc_mul.argtypes = [P, P, P]
         _lib.orc_binary.argtypes = [P, P, P, c_int]
+        _lib.orc_unary.argtypes = [P, P, c_int]
+        _lib.orc_unary_out_dtype.argtypes = [c_int, c_int]
         _lib.orc_reduce_out_shape.argtypes = [P, c_int, c_int, I4, I4]
         _lib.orc_reduce.argtypes = [P, P, c_int, c_int]
         _lib.orc_cast.argtypes = [P, P]
@@ -131,6 +133,17 @@ def mul(a, b):
         raise ValueError('mul: shapes do not broadcast')
     to, out = _alloc(list(shape), nd.value, dt.value)
     assert lib().orc_mul(ctypes.byref(ta), ctypes.byref(tb), ctypes.byref(to)) == 0
+    return out
+
+
+ABS, ANGLE, CONJ, REALPART, IMAGPART = 0, 1, 2, 3, 4
+
+
+def unary(x, op):
+    tx, x = _wrap(x)
+    dt = lib().orc_unary_out_dtype(NP_TO_DT[x.dtype], op)
+    to, out = _alloc([1] * (4 - x.ndim) + list(x.shape), x.ndim, dt)
+    assert lib().orc_unary(ctypes.byref(tx), ctypes.byref(to), op) == 0
     return out
 
 

@@ -73,6 +73,12 @@ class Ref:
             f = getattr(L, name)
             f.argtypes = [c_void_p, TP, TP, c_int, c_bool]
             f.restype = TP
+        L.dsc_abs.argtypes = [c_void_p, TP, TP]
+        L.dsc_abs.restype = TP
+        for name in ('dsc_angle', 'dsc_conj', 'dsc_real', 'dsc_imag'):
+            f = getattr(L, name)
+            f.argtypes = [c_void_p, TP]
+            f.restype = TP
         L.dsc_cast.argtypes = [c_void_p, TP, c_uint8]
         L.dsc_cast.restype = TP
         self.ctx = L.dsc_ctx_init(main_mem, scratch_mem)
@@ -129,6 +135,17 @@ class Ref:
         f = getattr(self.L, 'dsc_' + ('add', 'sub', 'mul', 'div')[op])
         out = self.take(f(self.ctx, ta, tb, None))
         self.free(ta, tb)
+        return out
+
+    def unary(self, x, op):
+        tx = self.put(x)
+        if op == 0:
+            to = self.L.dsc_abs(self.ctx, tx, None)
+        else:
+            to = getattr(self.L, 'dsc_' + ('', 'angle', 'conj', 'real', 'imag')[op])(self.ctx, tx)
+        same = ctypes.cast(to, c_void_p).value == ctypes.cast(tx, c_void_p).value     # conj / real of a real tensor return x
+        out = self.take(to, free=not same)
+        self.free(tx)
         return out
 
     def reduce(self, x, op, axis=-1, keepdims=True):

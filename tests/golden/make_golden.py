@@ -154,6 +154,13 @@ def main():
                 a, b = rnd(rng, sa, NP[da]), rnd(rng, sb, NP[db])
                 add('binary', name, (a, b), R.binary(a, b, op))
 
+    # ---- abs / angle / conj / real / imag of spectra and of real tensors
+    for dt in ('f32', 'f64', 'c32', 'c64'):
+        for shape in ((9,), (6, 33)):
+            x = rnd(rng, shape, NP[dt])
+            for op, name in enumerate(('abs', 'angle', 'conj', 'real', 'imag')):
+                add('unary', name, x, R.unary(x, op))
+
     for group, g in arrays.items():
         np.savez_compressed(os.path.join(HERE, f'{group}.npz'), **g)
         print(group, len(g), 'arrays', os.path.getsize(os.path.join(HERE, f'{group}.npz')) // 1024, 'KiB')

@@ -59,6 +59,19 @@ def test_golden_add_sub_div(dsc, golden):
     assert np.allclose((a / 2).numpy(), np.arange(6, dtype=np.float32).reshape(2, 3) / 2)
 
 
+def test_golden_unary(dsc, golden):
+    """abs / angle / conj / real / imag (dsc.cpp:1480-1622) incl. the dtype rules and the
+    'real input comes back as itself' rule of conj / real."""
+    f = {'abs': dsc.absolute, 'angle': dsc.angle, 'conj': dsc.conj, 'real': dsc.real, 'imag': dsc.imag}
+    for rec, xs, y in golden.cases('unary'):
+        got = f[rec['op']](dsc.from_numpy(xs[0])).numpy()
+        assert got.dtype == y.dtype and got.shape == y.shape, rec['key']
+        tol = 1e-5 if y.dtype in (np.float32, np.complex64) else 1e-12
+        assert np.allclose(got, y, rtol=tol, atol=tol), rec['key']
+    x = dsc.from_numpy(np.ones(4, np.float32))
+    assert dsc.conj(x)._c_ptr.contents.data == x._c_ptr.contents.data          # same buffer, second handle
+
+
 def test_golden_reductions(dsc, golden):
     for rec, xs, y in golden.cases('reduce'):
         got = getattr(dsc, rec['op'])(dsc.from_numpy(xs[0]), axis=rec['axis'], keepdims=rec['keepdims']).numpy()

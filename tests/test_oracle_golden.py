@@ -108,3 +108,14 @@ def test_add_sub_div(golden):
         _check(got, y, f"{rec['key']} {xs[0].dtype}{xs[0].shape} {rec['op']} {xs[1].dtype}{xs[1].shape}")
         n += 1
     assert n == 60
+
+
+def test_unary_spectrum_consumers(golden):
+    ops = {'abs': port.ABS, 'angle': port.ANGLE, 'conj': port.CONJ, 'real': port.REALPART, 'imag': port.IMAGPART}
+    n = 0
+    for rec, xs, y in golden.cases('unary'):
+        got = port.unary(xs[0], ops[rec['op']])
+        assert got.dtype == y.dtype and got.shape == y.shape, rec['key']
+        assert np.allclose(got, y, rtol=2e-6 if y.dtype == np.float32 or y.dtype == np.complex64 else 4e-15, atol=1e-30), rec['key']
+        n += 1
+    assert n == 40

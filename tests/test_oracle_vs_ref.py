@@ -69,6 +69,10 @@ def test_mul_reduce_cast():
                     same(port.binary(a, b, op), R.binary(a, b, op), np.result_type(da))
             x = rnd(rng, (3, 4), da)
             assert np.array_equal(port.cast(x, db), R.cast(x, db))
+        for op in range(5):
+            xu = rnd(rng, (5, 7), da)
+            pu, ru = port.unary(xu, op), R.unary(xu, op)
+            assert pu.dtype == ru.dtype and np.array_equal(pu, ru)
     for dt in DTS:
         for axis in range(-3, 3):
             for keep in (True, False):
