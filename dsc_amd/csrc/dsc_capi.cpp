@@ -296,6 +296,22 @@ static dsc_tensor *binary_entry(dsc_ctx *ctx, dsc_tensor *xa, dsc_tensor *xb, ds
         g.a_stride[i] = xa->shape[i] < shape[i] ? 0 : xa->stride[i];     // dsc_iter.h:71-73
         g.b_stride[i] = xb->shape[i] < shape[i] ? 0 : xb->stride[i];
     }
+    // index fast paths: equal shapes, or one operand spanning exactly the trailing dims of the output
+    // (e.g. a [B, K] spectrum times a [K] filter): no per-element index decomposition
+    auto trailing = [&](const dsc_tensor *small) {
+        bool seen_full = false;                       // shape must be 1,..,1,d_k,..,d_3 with the d's equal to the output's
+        for (int i = 0; i < DSC_MAX_DIMS; ++i) {
+            if (small->shape[i] == shape[i] && (shape[i] != 1 || seen_full)) seen_full = true;
+            else if (small->shape[i] == 1 && !seen_full) continue;
+            else if (small->shape[i] != shape[i]) return false;
+        }
+        return true;
+    };
+    g.fast = 0;
+    g.small_ne = 1;
+    if (xa->ne == out->ne && xb->ne == out->ne) g.fast = 1;
+    else if (xa->ne == out->ne && trailing(xb)) { g.fast = 2; g.small_ne = xb->ne; }
+    else if (xb->ne == out->ne && trailing(xa)) { g.fast = 3; g.small_ne = xa->ne; }
     dsc_launch_binary(ca->data, cb->data, out->data, out_dtype, op, g, ctx->stream);
 
     if (ca != xa) drop_scratch_tensor(ctx, ca);

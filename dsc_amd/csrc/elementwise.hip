@@ -69,6 +69,16 @@ __device__ __forceinline__ T apply(T a, T b) {
     }
 }
 
+// fast index paths: tensors have at most 2^31 - 1 elements (int ne), so 32-bit arithmetic suffices
+template<typename T, int OP, int FAST>
+__global__ void binary_fast_kernel(const T *a, const T *b, T *out, unsigned ne, unsigned small_ne) {
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < ne; i += gridDim.x * blockDim.x) {
+        const unsigned ia = FAST == 3 ? i % small_ne : i;
+        const unsigned ib = FAST == 2 ? i % small_ne : i;
+        out[i] = apply<T, OP>(a[ia], b[ib]);
+    }
+}
+
 template<typename T, int OP>
 __global__ void binary_kernel(const T *a, const T *b, T *out, const dsc_bcast_args g) {
     const long long s3 = g.out_shape[3];
@@ -89,10 +99,24 @@ __global__ void binary_kernel(const T *a, const T *b, T *out, const dsc_bcast_ar
     }
 }
 
+template<typename T, int OP>
+bool binary_fast(const T *pa, const T *pb, T *po, const dsc_bcast_args &g, dim3 grid, hipStream_t s) {
+    if (g.a_scalar || g.b_scalar || g.fast == 0) return false;
+    const unsigned ne = (unsigned) g.ne, sm = (unsigned) g.small_ne;
+    if (g.fast == 1) hipLaunchKernelGGL((binary_fast_kernel<T, OP, 1>), grid, dim3(256), 0, s, pa, pb, po, ne, sm);
+    else if (g.fast == 2) hipLaunchKernelGGL((binary_fast_kernel<T, OP, 2>), grid, dim3(256), 0, s, pa, pb, po, ne, sm);
+    else hipLaunchKernelGGL((binary_fast_kernel<T, OP, 3>), grid, dim3(256), 0, s, pa, pb, po, ne, sm);
+    return true;
+}
+
 template<typename T>
 void binary_typed(const void *a, const void *b, void *out, int op, const dsc_bcast_args &g, dim3 grid, hipStream_t s) {
     const T *pa = (const T *) a, *pb = (const T *) b;
     T *po = (T *) out;
+    if (op == 0 && binary_fast<T, 0>(pa, pb, po, g, grid, s)) return;
+    if (op == 1 && binary_fast<T, 1>(pa, pb, po, g, grid, s)) return;
+    if (op == 2 && binary_fast<T, 2>(pa, pb, po, g, grid, s)) return;
+    if (op == 3 && binary_fast<T, 3>(pa, pb, po, g, grid, s)) return;
     switch (op) {
         case 0: hipLaunchKernelGGL((binary_kernel<T, 0>), grid, dim3(256), 0, s, pa, pb, po, g); break;
         case 1: hipLaunchKernelGGL((binary_kernel<T, 1>), grid, dim3(256), 0, s, pa, pb, po, g); break;
