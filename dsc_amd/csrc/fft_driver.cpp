@@ -90,7 +90,9 @@ extern "C" dsc_fft_plan *dsc_plan_fft(dsc_ctx *ctx, int n, dsc_fft_type fft_type
     const bool regs64k = fft_type == DSC_FFT_REAL && twd == DSC_F32 && fft_n == 32768;
     const size_t full_bytes = DSC_ALIGN_UP((size_t) fft_n * 2 * real_sz, DSC_DEVICE_ALIGN);
     const size_t real_bytes = fft_type == DSC_FFT_REAL ? DSC_ALIGN_UP(((size_t) fft_n + 1) * 2 * real_sz, DSC_DEVICE_ALIGN) : 0;
-    const size_t aux_bytes = regs64k ? DSC_ALIGN_UP(dsc_r2c64k_table_bytes(), DSC_DEVICE_ALIGN) : 0;
+    const bool regs256k = fft_type == DSC_FFT_REAL && twd == DSC_F64 && fft_n == 131072;
+    const size_t aux_bytes = regs64k ? DSC_ALIGN_UP(dsc_r2c64k_table_bytes(), DSC_DEVICE_ALIGN)
+                           : regs256k ? DSC_ALIGN_UP(dsc_r2c256k_table_bytes(), DSC_DEVICE_ALIGN) : 0;
     const size_t total = full_bytes + real_bytes + aux_bytes;
 
     std::vector<char> host(total, 0);
@@ -101,7 +103,8 @@ extern "C" dsc_fft_plan *dsc_plan_fft(dsc_ctx *ctx, int n, dsc_fft_type fft_type
         fill_roots((double *) host.data(), fft_n, fft_n);
         if (real_bytes) fill_roots((double *) (host.data() + full_bytes), (long long) fft_n + 1, 2LL * fft_n);
     }
-    if (aux_bytes) dsc_r2c64k_build_tables(host.data() + full_bytes + real_bytes);
+    if (regs64k) dsc_r2c64k_build_tables(host.data() + full_bytes + real_bytes);
+    if (regs256k) dsc_r2c256k_build_tables(host.data() + full_bytes + real_bytes);
 
     plan = new dsc_fft_plan();
     plan->n = fft_n;
@@ -253,6 +256,31 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
         if (j.mode == DSC_MODE_C2R_PACKED && j.in_len == 32769 && j.x->shape[j.slot] == 32769) {
             dsc_launch_irfft64k(j.x->data, (float *) j.out->data, (int) n_lines, plan->tw_aux, ctx->n_cu, ctx->stream);
             ctx->last_fft_path = "c2r_64k_regs";
+            return;
+        }
+    }
+
+    // 262144-point f64 real transforms (config 5): radix-8 + register-resident 16384-point passes
+    if (!sp && packed && j.L == 131072 && inner == 1 && plan->tw_aux != nullptr) {
+        const bool fwd = j.mode == DSC_MODE_R2C_PACKED && j.in_len == 262144 && j.x->shape[j.slot] == 262144;
+        const bool inv = j.mode == DSC_MODE_C2R_PACKED && j.in_len == 131073 && j.x->shape[j.slot] == 131073;
+        if (fwd || inv) {
+            const size_t row_bytes = (size_t) 131072 * 16;
+            ctx->scratch.reset();
+            long long chunk = (long long) ((ctx->scratch.capacity() - DSC_DEVICE_ALIGN) / row_bytes);
+            if (chunk < 1) DSC_LOG_FATAL("scratch arena too small: a 262144-point f64 transform needs 2 MB of scratch per row");
+            if (chunk > n_lines) chunk = n_lines;
+            char *work = ctx->scratch.alloc((size_t) chunk * row_bytes);
+            for (long long q = 0; q < n_lines; q += chunk) {
+                const long long nl = n_lines - q < chunk ? n_lines - q : chunk;
+                if (fwd)
+                    dsc_launch_rfft256k_f64((const double *) j.x->data + q * 262144, (char *) j.out->data + (size_t) q * 131073 * 16, nl,
+                                            work, plan->tw_aux, plan->tw_real, ctx->n_cu, ctx->stream);
+                else
+                    dsc_launch_irfft256k_f64((const char *) j.x->data + (size_t) q * 131073 * 16, (double *) j.out->data + q * 262144, nl,
+                                             work, plan->tw_aux, plan->tw_real, ctx->n_cu, ctx->stream);
+            }
+            ctx->last_fft_path = fwd ? "r2c_256k_f64_regs" : "c2r_256k_f64_regs";
             return;
         }
     }

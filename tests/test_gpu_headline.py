@@ -168,3 +168,26 @@ def test_bench_two_ranks_on_one_gpu():
     assert j['n_gpus'] == 2 and j['config']['global_batch'] == 2048 and j['config']['kernel_path'] == 'r2c_64k_regs'
     assert j['parity']['rel_l2_vs_cpu_oracle'] <= 1e-5
     assert j['roofline']['achieved'] > 0 and 'cpu_baseline' not in j
+
+
+def test_f64_262144_register_path(dsc):
+    """BASELINE config 5 (f64 N=262144): radix-8 pass + register-resident 16384-point passes +
+    post-pass.  Parity 1e-12 vs the oracle, round trip, path check, odd row counts (chunking)."""
+    from oracle import port
+    rng = np.random.default_rng(55)
+    for rows in (1, 3, 37):
+        x = rng.standard_normal((rows, 262144))
+        X = dsc.rfft(dsc.from_numpy(x))
+        assert dsc.last_fft_path() == 'r2c_256k_f64_regs'
+        got = X.numpy()
+        for r in sorted({0, rows - 1}):
+            assert_close(got[r], port.rfft(x[r]), what=f'f64 rfft row {r}/{rows}')
+        assert rel_l2(got, np.fft.rfft(x, axis=-1)) <= 1e-14
+        assert np.all(got[:, 0].imag == 0) and np.all(got[:, -1].imag == 0)
+        Xq = got.copy()
+        Xq[:, 0] += 2j                                     # imaginary parts of bins 0 and n are ignored (dsc_fft.h:227-228)
+        back = dsc.irfft(dsc.from_numpy(Xq))
+        assert dsc.last_fft_path() == 'c2r_256k_f64_regs'
+        bh = back.numpy()
+        assert_close(bh[0], port.irfft(Xq[0]), what='f64 irfft')
+        assert rel_l2(bh, x) <= 1e-14
