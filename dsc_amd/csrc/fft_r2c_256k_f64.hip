@@ -297,39 +297,42 @@ __global__ void radix8_out_kernel(const cd *__restrict__ work, cd *__restrict__ 
 // where bin k of the 131072-point spectrum sits after pass B
 __device__ __forceinline__ long long zidx(int k) { return (long long) (k & 7) * kSeg + (k >> 3); }
 
-// C (forward post-pass, dsc_fft.h:199-225): X[k] = h1 + w h2 from Z[k], Z[L-k], k = 0..L
-__global__ void r2c_post_f64_kernel(const cd *__restrict__ work, cd *__restrict__ out, long long n_rows, const cd *__restrict__ tw_real) {
-    const long long bins = (long long) kL + 1;
-    const long long total = n_rows * bins;
-    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long) gridDim.x * blockDim.x) {
-        const long long row = i / bins;
-        const int k = (int) (i - row * bins);
-        const cd *z = work + row * kL;
-        const cd a = ld(z + zidx(k == kL ? 0 : k)), b = ld(z + zidx(k == 0 ? 0 : kL - k));
+// C (forward post-pass, dsc_fft.h:199-225).  One thread per PAIR of bins (k, L-k), k = 0..L/2: every
+// Z element is read once, both outputs leave as coalesced 16-B stores (ascending / descending).
+//   s = a + conj b, d = a - conj b, wq = -(i/2) W_{2L}^k:  X[k] = s/2 + wq d,  X[L-k] = conj(s/2 - wq d)
+__global__ void r2c_post_f64_kernel(const cd *__restrict__ work, cd *__restrict__ out, const cd *__restrict__ tw_real) {
+    const long long row = blockIdx.y;
+    const cd *z = work + row * kL;
+    cd *o = out + row * (kL + 1LL);
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k <= kL / 2; k += gridDim.x * blockDim.x) {
+        const cd a = ld(z + zidx(k)), b = ld(z + zidx(k == 0 ? 0 : kL - k));
         const cd w = ld(tw_real + k);
-        const double h1r = 0.5 * (a.x + b.x), h1i = 0.5 * (a.y - b.y);
-        const double h2r = 0.5 * (a.y + b.y), h2i = -0.5 * (a.x - b.x);
-        cd r = cd{h1r + w.x * h2r - w.y * h2i, h1i + w.x * h2i + w.y * h2r};
-        if (k == 0 || k == kL) r.y = 0.0;                     // dsc_fft.h:221-225 stores exact zeros
-        st(out + row * bins + k, r);
+        const cd wq = cd{0.5 * w.y, -0.5 * w.x};
+        const cd sm = cd{a.x + b.x, a.y - b.y}, d = cd{a.x - b.x, a.y + b.y};
+        const cd wd = cmul(d, wq);
+        cd xk = cd{0.5 * sm.x + wd.x, 0.5 * sm.y + wd.y};
+        cd xm = cd{0.5 * sm.x - wd.x, wd.y - 0.5 * sm.y};
+        if (k == 0) { xk.y = 0.0; xm.y = 0.0; }              // dsc_fft.h:221-225 stores exact zeros
+        st(o + k, xk);
+        st(o + kL - k, xm);
     }
 }
 
-// C' (inverse pre-pass, dsc_fft.h:199-228): Z[k] = h1 + conj(w) h2 from Y[k], Y[L-k], k = 0..L-1
-__global__ void c2r_pre_f64_kernel(const cd *__restrict__ in, cd *__restrict__ work, long long n_rows, const cd *__restrict__ tw_real) {
-    const long long bins = (long long) kL + 1;
-    const long long total = n_rows * kL;
-    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long) gridDim.x * blockDim.x) {
-        const long long row = i >> 17;
-        const int k = (int) (i & (kL - 1));
-        const cd *y = in + row * bins;
+// C' (inverse pre-pass, dsc_fft.h:199-228), one thread per pair (k, L-k), k = 0..L/2:
+//   Z[k] = s/2 + wq d,  Z[L-k] = conj(s/2 - wq d),  wq = (i/2) conj(W_{2L}^k)
+__global__ void c2r_pre_f64_kernel(const cd *__restrict__ in, cd *__restrict__ work, const cd *__restrict__ tw_real) {
+    const long long row = blockIdx.y;
+    const cd *y = in + row * (kL + 1LL);
+    cd *z = work + row * kL;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k <= kL / 2; k += gridDim.x * blockDim.x) {
         cd a = ld(y + k), b = ld(y + kL - k);
         if (k == 0) { a.y = 0.0; b.y = 0.0; }                 // dsc_fft.h:227-228 reads the real parts only
         const cd w = ld(tw_real + k);
-        const double h1r = 0.5 * (a.x + b.x), h1i = 0.5 * (a.y - b.y);
-        const double h2r = -0.5 * (a.y + b.y), h2i = 0.5 * (a.x - b.x);
-        const double wr = w.x, wi = -w.y;
-        st(work + row * kL + zidx(k), cd{h1r + wr * h2r - wi * h2i, h1i + wr * h2i + wi * h2r});
+        const cd wq = cd{0.5 * w.y, 0.5 * w.x};
+        const cd sm = cd{a.x + b.x, a.y - b.y}, d = cd{a.x - b.x, a.y + b.y};
+        const cd wd = cmul(d, wq);
+        st(z + zidx(k), cd{0.5 * sm.x + wd.x, 0.5 * sm.y + wd.y});
+        if (k != 0) st(z + zidx(kL - k), cd{0.5 * sm.x - wd.x, wd.y - 0.5 * sm.y});
     }
 }
 
@@ -380,7 +383,7 @@ void dsc_launch_rfft256k_f64(const double *x, void *X, long long rows, void *wor
     const long long n_seg = rows * 8;
     const int grid = (int) (n_seg < n_cu ? n_seg : n_cu);
     hipLaunchKernelGGL(fft16k_f64_kernel<false>, dim3(grid), dim3(kThreadsB), kLdsBytesB, stream, (cd *) work, n_seg, (const cd *) aux);
-    hipLaunchKernelGGL(r2c_post_f64_kernel, flat_grid(rows * (kL + 1LL)), dim3(256), 0, stream, (const cd *) work, (cd *) X, rows,
+    hipLaunchKernelGGL(r2c_post_f64_kernel, dim3(kL / 2 / 256 / 4, (unsigned) rows), dim3(256), 0, stream, (const cd *) work, (cd *) X,
                        (const cd *) tw_real);
 }
 
@@ -394,7 +397,7 @@ void dsc_launch_irfft256k_f64(const void *X, double *x, long long rows, void *wo
         (void) hipFuncSetAttribute((const void *) fft16k_f64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytesB);
         attr_set = true;
     }
-    hipLaunchKernelGGL(c2r_pre_f64_kernel, flat_grid(rows * (long long) kL), dim3(256), 0, stream, (const cd *) X, (cd *) work, rows,
+    hipLaunchKernelGGL(c2r_pre_f64_kernel, dim3(kL / 2 / 256 / 4, (unsigned) rows), dim3(256), 0, stream, (const cd *) X, (cd *) work,
                        (const cd *) tw_real);
     const long long n_seg = rows * 8;
     const int grid = (int) (n_seg < n_cu ? n_seg : n_cu);
