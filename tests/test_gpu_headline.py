@@ -191,3 +191,41 @@ def test_f64_262144_register_path(dsc):
         bh = back.numpy()
         assert_close(bh[0], port.irfft(Xq[0]), what='f64 irfft')
         assert rel_l2(bh, x) <= 1e-14
+
+
+@pytest.mark.parametrize('n', [4096, 8192, 16384, 32768])
+def test_mid_size_register_path(dsc, n):
+    """Real lengths 4096 .. 32768 (complex 2048 .. 16384) of contiguous full rows run in
+    fft_regs_mid.hip; row counts that are not a multiple of the lines-per-workgroup exercise
+    the partially filled last group.  rfft / irfft / fft / ifft against the oracle."""
+    from oracle import port
+    rng = np.random.default_rng(n)
+    for rows in (1, 5, 67):
+        x = rng.standard_normal((rows, n)).astype(np.float32)
+        X = dsc.rfft(dsc.from_numpy(x))
+        assert dsc.last_fft_path() == 'regs_mid'
+        got = X.numpy()
+        for r in sorted({0, rows // 2, rows - 1}):
+            assert_close(got[r], port.rfft(x[r]), what=f'rfft n={n} row {r}/{rows}')
+        assert rel_l2(got, np.fft.rfft(x.astype(np.float64), axis=-1)) <= 1e-6
+        assert np.all(got[:, 0].imag == 0) and np.all(got[:, -1].imag == 0)
+        Xq = got.copy()
+        Xq[:, 0] += 2j                                     # ignored by dsc_fft.h:227-228
+        Xq[:, -1] -= 3j
+        back = dsc.irfft(dsc.from_numpy(Xq))
+        assert dsc.last_fft_path() == 'regs_mid'
+        bh = back.numpy()
+        for r in sorted({0, rows - 1}):
+            assert_close(bh[r], port.irfft(Xq[r]), what=f'irfft n={n} row {r}/{rows}')
+        assert rel_l2(bh, x) <= 1e-6
+        # complex transforms of length n/2
+        z = (rng.standard_normal((rows, n // 2)) + 1j * rng.standard_normal((rows, n // 2))).astype(np.complex64)
+        Z = dsc.fft(dsc.from_numpy(z))
+        assert dsc.last_fft_path() == 'regs_mid'
+        zh = Z.numpy()
+        assert_close(zh[rows - 1], port.fft(z[rows - 1]), what=f'fft n={n // 2}')
+        assert rel_l2(zh, np.fft.fft(z.astype(np.complex128), axis=-1)) <= 1e-6
+        zb = dsc.ifft(Z)
+        assert dsc.last_fft_path() == 'regs_mid'
+        assert_close(zb.numpy()[0], port.ifft(zh[0]), what=f'ifft n={n // 2}')
+        assert rel_l2(zb.numpy(), z) <= 1e-6
