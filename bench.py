@@ -95,8 +95,11 @@ def cpu_baseline(rows=1024, reps=5, warm=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=50)
+    ap.add_argument('--ramp-ms', type=float, default=100.0,
+                    help='untimed launches of the same step for this long before the warm-up steps: the GPU clocks need tens of '
+                         'milliseconds of load to come back up after the host-side parity check (0 disables)')
     ap.add_argument('--batch', type=int, default=BATCH, help='rows per GPU (default: BASELINE config 2)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-allgather', action='store_true')
@@ -163,6 +166,13 @@ def main():
         want = port.rfft(x_host[:4])
         parity = float(np.linalg.norm(first - want) / np.linalg.norm(want))
 
+    if not args.dry_run and args.ramp_ms > 0:
+        # clock ramp (untimed, before the W warm-up steps): the parity check above left the GPU idle
+        t_ramp = time.perf_counter()
+        while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
+            for _ in range(10):
+                step()
+            dsc.synchronize()
     for _ in range(args.warmup):
         step()
     barrier_sync()
@@ -235,7 +245,7 @@ def main():
             'config': {'workload': f'1-D rfft f32 N={N_FFT} batch={rows} per GPU (BASELINE configs[1]), '
                                    f'inputs resident in HBM, standard_normal seed 1234+rank',
                        'n_fft': N_FFT, 'batch_per_gpu': rows, 'global_batch': world * rows, 'parallelism': f'batch-shard x{world}',
-                       'kernel_path': path},
+                       'kernel_path': path, 'clock_ramp_ms_untimed': 0.0 if args.dry_run else args.ramp_ms},
         }
         if not args.dry_run:
             achieved = rows * BYTES_PER_ROW / (kernel_ms * 1e-3) / 1e9
