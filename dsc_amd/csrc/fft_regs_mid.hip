@@ -111,21 +111,26 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-template<int B> struct mid_cfg {
-    static constexpr int T = 32 * B;                 // threads per line
-    static constexpr int L = 1024 * B;               // complex length
-    static constexpr int G = B >= 16 ? 1 : B >= 8 ? 16 / B : 8 / B;   // lines per workgroup: 512 threads (B = 8, 16), 1024 (B = 32) or 256
-    static constexpr int WAVES_PER_EU = B >= 32 ? 4 : B >= 8 ? 4 : 2; // two 512-thread groups per CU (<= 128 VGPRs), or one of 1024
-    static constexpr int NT = T * G;
+// TWO = false: L = 1024 B, three passes (32 x 32 x B), T = 32 B threads per line.
+// TWO = true:  L = 32 B,   two passes  (32 x B),       T = B threads per line (a wave holds 64 / B lines).
+template<int B, bool TWO> struct mid_cfg {
+    static constexpr int T = TWO ? B : 32 * B;       // threads per line
+    static constexpr int L = 32 * T;                 // complex length
+    static constexpr int COLS = TWO ? 32 : 1024;     // columns entering the last pass (DFT_B down each)
+    static constexpr int NT = TWO ? 256 : B >= 32 ? 1024 : B >= 8 ? 512 : 256;
+    static constexpr int G = NT / T;                 // lines per workgroup
+    static constexpr int WAVES_PER_EU = TWO ? 2 : B >= 8 ? 4 : 2;   // VGPR budget: <= 128 where two 512-thread groups share a CU
     static constexpr int P1 = 33;                    // exchange-1 row pitch (values): odd
-    static constexpr int P2 = B + 1;                 // exchange-2 row pitch
+    static constexpr int P2 = B + 1;                 // last-exchange row pitch
     static constexpr int SP = L + 1;                 // staging pitch per line (bins 0 .. L)
-    static constexpr int PLANE = G * 1024 * P2;      // >= G*T*P1 and >= G*SP
-    static constexpr int CPT = 32 / B;               // columns per thread in pass 3
+    static constexpr int PLANE = G * COLS * P2;      // >= G*T*P1 (three-pass) and >= G*SP
+    static constexpr int CPT = 32 / B;               // columns per thread in the last pass
+    static constexpr int TABLE = TWO ? L : 1024;     // LDS twiddle table: W_L^m (two-pass) or W_1024^m
+    static constexpr int TABLE_STRIDE = TWO ? 1 : B;
 };
 
-template<typename R, int B>
-constexpr size_t mid_lds_bytes() { return ((size_t) mid_cfg<B>::PLANE + 2048) * sizeof(R); }
+template<typename R, int B, bool TWO>
+constexpr size_t mid_lds_bytes() { return ((size_t) mid_cfg<B, TWO>::PLANE + 2 * mid_cfg<B, TWO>::TABLE) * sizeof(R); }
 
 typedef unsigned int u2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
@@ -151,45 +156,47 @@ __device__ __forceinline__ void buf_store(cpx<double> a, __amdgpu_buffer_rsrc_t 
 }
 
 // MODE: DSC_MODE_C2C, DSC_MODE_R2C_PACKED (forward only), DSC_MODE_C2R_PACKED (inverse only)
-template<typename R, int B, int MODE, bool INV>
-__global__ __launch_bounds__(mid_cfg<B>::NT, mid_cfg<B>::WAVES_PER_EU) void fft_mid_kernel(
+template<typename R, int B, bool TWO, int MODE, bool INV>
+__global__ __launch_bounds__((mid_cfg<B, TWO>::NT), (mid_cfg<B, TWO>::WAVES_PER_EU)) void fft_mid_kernel(
     const cpx<R> *__restrict__ in, cpx<R> *__restrict__ out, long long n_lines, const cpx<R> *__restrict__ tw_full,
     const cpx<R> *__restrict__ tw_real, R scale) {
     using C = cpx<R>;
-    using cfg = mid_cfg<B>;
+    using cfg = mid_cfg<B, TWO>;
     constexpr int T = cfg::T, L = cfg::L, G = cfg::G, NT = cfg::NT, P1 = cfg::P1, P2 = cfg::P2, SP = cfg::SP, CPT = cfg::CPT;
+    constexpr int COLS = cfg::COLS;
     constexpr int LOGB = ilog2(B);
     constexpr int CB = (int) sizeof(C);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     R *plane = (R *) lds_raw;
-    C *w1024 = (C *) (plane + cfg::PLANE);
+    C *wtab = (C *) (plane + cfg::PLANE);
 
     const int tid = threadIdx.x;
-    const int g = __builtin_amdgcn_readfirstlane(tid / T);          // a wave never straddles two lines (T >= 64)
+    const int g = T >= 64 ? __builtin_amdgcn_readfirstlane(tid / T) : tid / T;      // line within the group
     const int t = tid - g * T;
-    const long long line = (long long) blockIdx.x * G + g;
-    const bool valid = line < n_lines;
-    const int hi = t / B, lo = t % B;
+    const long long line0 = (long long) blockIdx.x * G;
+    const long long left = n_lines - line0;
+    const int n_valid = left < G ? (int) left : G;                  // lines past the end read zeros, their stores are dropped
+    const int hi = TWO ? 0 : t / B, lo = TWO ? t : t % B;
     constexpr int in_pitch = MODE == DSC_MODE_C2R_PACKED ? L + 1 : L;
     constexpr int out_pitch = MODE == DSC_MODE_R2C_PACKED ? L + 1 : L;
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *) (in + (valid ? line : 0) * in_pitch), 0,
-                                                                         valid ? in_pitch * CB : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *) (out + (valid ? line : 0) * out_pitch), 0,
-                                                                          valid ? out_pitch * CB : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *) (in + line0 * in_pitch), 0, n_valid * in_pitch * CB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *) (out + line0 * out_pitch), 0, n_valid * out_pitch * CB, 0x00020000);
+    const int vin = (g * in_pitch + t) * CB;                       // byte offset of element t of this thread's line
+    const int vout = (g * out_pitch + t) * CB;
     R *stage = plane + g * SP;
 
-    for (int i = tid; i < 1024; i += NT) w1024[i] = tw_full[(long long) i * B];     // W_1024^m = W_L^{B m}
+    for (int i = tid; i < cfg::TABLE; i += NT) wtab[i] = tw_full[(long long) i * cfg::TABLE_STRIDE];    // W_1024^m = W_L^{B m}
 
     C v[32];
 #pragma unroll
-    for (int j1 = 0; j1 < 32; ++j1) v[j1] = buf_load(rin, t * CB, j1 * T * CB, R{});          // z[T j1 + t]
+    for (int j1 = 0; j1 < 32; ++j1) v[j1] = buf_load(rin, vin, j1 * T * CB, R{});             // z[T j1 + t]
 
     if constexpr (MODE == DSC_MODE_C2R_PACKED) {
         // Z[k] = (a + conj b)/2 + wq (a - conj b), a = Y[k], b = Y[L-k], wq = (i/2) conj(W_2L^k), for the
         // thread's own k = T j1 + t; b comes through the staging plane, one component at a time.
         const C wbase = tw_real[t];
         C yl = C{(R) 0, (R) 0};
-        if (t == 0) { yl = buf_load(rin, L * CB, 0, R{}); v[0].y = (R) 0; yl.y = (R) 0; }   // dsc_fft.h:227-228: real parts only at k = 0
+        if (t == 0) { yl = buf_load(rin, vin, L * CB, R{}); v[0].y = (R) 0; yl.y = (R) 0; }   // dsc_fft.h:227-228: real parts only at k = 0
         R dx[32];
         R *up = stage + t;                          // up[T j1]         = stage[k]
         const R *dn = stage + (L - 31 * T) - t;     // dn[T (31 - j1)]  = stage[L - k]
@@ -219,18 +226,18 @@ __global__ __launch_bounds__(mid_cfg<B>::NT, mid_cfg<B>::WAVES_PER_EU) void fft_
             v[j1] = C{zx, zy};
         }
     }
-    __syncthreads();                // w1024 visible; staging reads done before the plane is reused
+    __syncthreads();                // twiddle table visible; staging reads done before the plane is reused
 
-    // ---- pass 1 over j1, twiddle W_1024^{j2 k1}
-    dft_n<R, INV, 32>(v);
-#pragma unroll
-    for (int k1 = 1; k1 < 32; ++k1) {
-        const C w = w1024[hi * k1];
-        v[brev(k1, 5)] = INV ? cmulc(v[brev(k1, 5)], w) : cmul(v[brev(k1, 5)], w);
-    }
-    // ---- exchange 1: (j2, j3)[k1] -> thread B k1 + j3, [j2]
     C u[32];
-    {
+    if constexpr (!TWO) {
+        // ---- pass 1 over j1, twiddle W_1024^{j2 k1}
+        dft_n<R, INV, 32>(v);
+#pragma unroll
+        for (int k1 = 1; k1 < 32; ++k1) {
+            const C w = wtab[hi * k1];
+            v[brev(k1, 5)] = INV ? cmulc(v[brev(k1, 5)], w) : cmul(v[brev(k1, 5)], w);
+        }
+        // ---- exchange 1: (j2, j3)[k1] -> thread B k1 + j3, [j2]
         R *wr = plane + (g * T + lo) * P1 + hi;
         const R *rd = plane + tid * P1;
 #pragma unroll
@@ -245,22 +252,34 @@ __global__ __launch_bounds__(mid_cfg<B>::NT, mid_cfg<B>::WAVES_PER_EU) void fft_
 #pragma unroll
         for (int m = 0; m < 32; ++m) u[m].y = rd[m];
         lds_barrier();
+    } else {
+#pragma unroll
+        for (int m = 0; m < 32; ++m) u[m] = v[m];                   // two-pass: the loaded index j1 is the pass-2 index
     }
     // ---- pass 2 over j2 (thread = (k1, j3) = (hi, lo)), twiddle W_L^{j3 k1} W_{32B}^{j3 k2}
     dft_n<R, INV, 32>(u);
     {
-        const C tw2_base = tw_full[hi * lo];
-        u[0] = INV ? cmulc(u[0], tw2_base) : cmul(u[0], tw2_base);
+        if constexpr (!TWO) {
+            const C tw2_base = tw_full[hi * lo];
+            u[0] = INV ? cmulc(u[0], tw2_base) : cmul(u[0], tw2_base);
 #pragma unroll
-        for (int k2 = 1; k2 < 32; ++k2) {
-            const C w = cmul(tw2_base, w1024[(32 / B) * lo * k2]);
-            u[brev(k2, 5)] = INV ? cmulc(u[brev(k2, 5)], w) : cmul(u[brev(k2, 5)], w);
+            for (int k2 = 1; k2 < 32; ++k2) {
+                const C w = cmul(tw2_base, wtab[(32 / B) * lo * k2]);
+                u[brev(k2, 5)] = INV ? cmulc(u[brev(k2, 5)], w) : cmul(u[brev(k2, 5)], w);
+            }
+        } else {
+#pragma unroll
+            for (int k2 = 1; k2 < 32; ++k2) {
+                const C w = wtab[lo * k2];                           // W_L^{j3 k2}
+                u[brev(k2, 5)] = INV ? cmulc(u[brev(k2, 5)], w) : cmul(u[brev(k2, 5)], w);
+            }
         }
-        // ---- exchange 2: row = column k' = k1 + 32 k2, col = j3; thread t reads columns t + T i
-        R *wr = plane + (g * 1024 + hi) * P2 + lo;
-        const R *rd = plane + (g * 1024 + t) * P2;
+        // ---- last exchange: row = column k' = k1 + 32 k2 (two-pass: k2), col = j3; thread t reads columns t + T i
+        constexpr int CS = TWO ? 1 : 32;
+        R *wr = plane + (g * COLS + hi) * P2 + lo;
+        const R *rd = plane + (g * COLS + t) * P2;
 #pragma unroll
-        for (int k2 = 0; k2 < 32; ++k2) wr[k2 * 32 * P2] = u[brev(k2, 5)].x;
+        for (int k2 = 0; k2 < 32; ++k2) wr[k2 * CS * P2] = u[brev(k2, 5)].x;
         lds_barrier();
 #pragma unroll
         for (int i = 0; i < CPT; ++i)
@@ -268,7 +287,7 @@ __global__ __launch_bounds__(mid_cfg<B>::NT, mid_cfg<B>::WAVES_PER_EU) void fft_
             for (int m = 0; m < B; ++m) v[i * B + m].x = rd[i * T * P2 + m];
         lds_barrier();
 #pragma unroll
-        for (int k2 = 0; k2 < 32; ++k2) wr[k2 * 32 * P2] = u[brev(k2, 5)].y;
+        for (int k2 = 0; k2 < 32; ++k2) wr[k2 * CS * P2] = u[brev(k2, 5)].y;
         lds_barrier();
 #pragma unroll
         for (int i = 0; i < CPT; ++i)
@@ -276,7 +295,7 @@ __global__ __launch_bounds__(mid_cfg<B>::NT, mid_cfg<B>::WAVES_PER_EU) void fft_
             for (int m = 0; m < B; ++m) v[i * B + m].y = rd[i * T * P2 + m];
         lds_barrier();
     }
-    // ---- pass 3 over j3: CPT DFTs of B points; v[i B + p] = bin k = (t + T i) + 1024 brev(p)
+    // ---- last pass over j3: CPT DFTs of B points; v[i B + p] = bin k = (t + T i) + COLS brev(p)
     dft_columns<R, INV, B>(v, std::make_integer_sequence<int, CPT>{});
 
     if constexpr (MODE != DSC_MODE_R2C_PACKED) {
@@ -285,7 +304,7 @@ __global__ __launch_bounds__(mid_cfg<B>::NT, mid_cfg<B>::WAVES_PER_EU) void fft_
 #pragma unroll
             for (int p = 0; p < B; ++p) {
                 const C r = v[i * B + p];
-                buf_store(C{r.x * scale, r.y * scale}, rout, t * CB, (T * i + 1024 * brev(p, LOGB)) * CB);
+                buf_store(C{r.x * scale, r.y * scale}, rout, vout, (T * i + COLS * brev(p, LOGB)) * CB);
             }
     } else {
         // packed-real post-pass (dsc_fft.h:199-225), one thread per PAIR (k, L-k), k = t + T i < L/2,
@@ -298,7 +317,7 @@ __global__ __launch_bounds__(mid_cfg<B>::NT, mid_cfg<B>::WAVES_PER_EU) void fft_
 #pragma unroll
         for (int i = 0; i < CPT; ++i)
 #pragma unroll
-            for (int p = 0; p < B; ++p) up[T * i + 1024 * brev(p, LOGB)] = v[i * B + p].x;
+            for (int p = 0; p < B; ++p) up[T * i + COLS * brev(p, LOGB)] = v[i * B + p].x;
         if (t == 0) stage[L] = v[0].x;                                    // Z[L] := Z[0]
         lds_barrier();
 #pragma unroll
@@ -308,10 +327,10 @@ __global__ __launch_bounds__(mid_cfg<B>::NT, mid_cfg<B>::WAVES_PER_EU) void fft_
 #pragma unroll
         for (int i = 0; i < CPT; ++i)
 #pragma unroll
-            for (int p = 0; p < B; ++p) up[T * i + 1024 * brev(p, LOGB)] = v[i * B + p].y;
+            for (int p = 0; p < B; ++p) up[T * i + COLS * brev(p, LOGB)] = v[i * B + p].y;
         if (t == 0) stage[L] = v[0].y;
         lds_barrier();
-        const int dn_voff = ((L - 15 * T) - t) * CB;
+        const int dn_voff = (g * out_pitch + (L - 15 * T) - t) * CB;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const R ay = up[T * i], by = dn[T * (15 - i)];
@@ -322,37 +341,37 @@ __global__ __launch_bounds__(mid_cfg<B>::NT, mid_cfg<B>::WAVES_PER_EU) void fft_
             C xk = C{(R) 0.5 * sx + wdx, (R) 0.5 * sy + wdy};
             C xm = C{(R) 0.5 * sx - wdx, wdy - (R) 0.5 * sy};
             if (i == 0 && t == 0) { xk.y = (R) 0; xm.y = (R) 0; }           // dsc_fft.h:221-225 stores exact zeros
-            buf_store(C{xk.x * scale, xk.y * scale}, rout, t * CB, T * i * CB);
+            buf_store(C{xk.x * scale, xk.y * scale}, rout, vout, T * i * CB);
             buf_store(C{xm.x * scale, xm.y * scale}, rout, dn_voff, T * (15 - i) * CB);
         }
         if (t == 0) {                                                     // k = L/2: a = b, W_2L^{L/2} = -i
             const R ay = stage[L / 2];
-            buf_store(C{amx * scale, -ay * scale}, rout, (L / 2) * CB, 0);
+            buf_store(C{amx * scale, -ay * scale}, rout, vout, (L / 2) * CB);
         }
     }
 }
 
-template<typename R, int B, int MODE, bool INV>
+template<typename R, int B, bool TWO, int MODE, bool INV>
 void launch_one(const void *in, void *out, long long n_lines, const void *tw_full, const void *tw_real, double scale, hipStream_t stream) {
-    using cfg = mid_cfg<B>;
-    constexpr size_t lds = mid_lds_bytes<R, B>();
+    using cfg = mid_cfg<B, TWO>;
+    constexpr size_t lds = mid_lds_bytes<R, B, TWO>();
     static bool attr_set = false;
     if (!attr_set) {
-        (void) hipFuncSetAttribute((const void *) fft_mid_kernel<R, B, MODE, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        (void) hipFuncSetAttribute((const void *) fft_mid_kernel<R, B, TWO, MODE, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         attr_set = true;
     }
     const long long groups = (n_lines + cfg::G - 1) / cfg::G;
-    hipLaunchKernelGGL((fft_mid_kernel<R, B, MODE, INV>), dim3((unsigned) groups), dim3(cfg::NT), lds, stream, (const cpx<R> *) in,
+    hipLaunchKernelGGL((fft_mid_kernel<R, B, TWO, MODE, INV>), dim3((unsigned) groups), dim3(cfg::NT), lds, stream, (const cpx<R> *) in,
                        (cpx<R> *) out, n_lines, (const cpx<R> *) tw_full, (const cpx<R> *) tw_real, (R) scale);
 }
 
-template<typename R, int B>
+template<typename R, int B, bool TWO>
 void launch_b(const void *in, void *out, long long n_lines, dsc_fft_mode mode, bool inverse, const void *tw_full, const void *tw_real,
               double scale, hipStream_t stream) {
-    if (mode == DSC_MODE_R2C_PACKED)      launch_one<R, B, DSC_MODE_R2C_PACKED, false>(in, out, n_lines, tw_full, tw_real, scale, stream);
-    else if (mode == DSC_MODE_C2R_PACKED) launch_one<R, B, DSC_MODE_C2R_PACKED, true>(in, out, n_lines, tw_full, tw_real, scale, stream);
-    else if (inverse)                     launch_one<R, B, DSC_MODE_C2C, true>(in, out, n_lines, tw_full, tw_real, scale, stream);
-    else                                  launch_one<R, B, DSC_MODE_C2C, false>(in, out, n_lines, tw_full, tw_real, scale, stream);
+    if (mode == DSC_MODE_R2C_PACKED)      launch_one<R, B, TWO, DSC_MODE_R2C_PACKED, false>(in, out, n_lines, tw_full, tw_real, scale, stream);
+    else if (mode == DSC_MODE_C2R_PACKED) launch_one<R, B, TWO, DSC_MODE_C2R_PACKED, true>(in, out, n_lines, tw_full, tw_real, scale, stream);
+    else if (inverse)                     launch_one<R, B, TWO, DSC_MODE_C2C, true>(in, out, n_lines, tw_full, tw_real, scale, stream);
+    else                                  launch_one<R, B, TWO, DSC_MODE_C2C, false>(in, out, n_lines, tw_full, tw_real, scale, stream);
 }
 
 }  // namespace
@@ -361,20 +380,23 @@ bool dsc_fft_regs_mid_supports(int L, dsc_fft_mode mode, bool single_precision) 
     if (!single_precision) return false;
     if (mode == DSC_MODE_R2C_CAST) return false;
     if (L == 32768) return mode == DSC_MODE_C2C;          // the packed-real 65536-point transforms have their own kernels
-    return L == 2048 || L == 4096 || L == 8192 || L == 16384;
+    return L == 256 || L == 512 || L == 1024 || L == 2048 || L == 4096 || L == 8192 || L == 16384;
 }
 
 void dsc_launch_fft_regs_mid(const void *in, void *out, long long n_lines, int L, dsc_fft_mode mode, bool inverse, const void *tw_full,
                              const void *tw_real, double scale, hipStream_t stream) {
     if (n_lines <= 0) return;
     switch (L) {
-        case 2048:  launch_b<float, 2>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
-        case 4096:  launch_b<float, 4>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
-        case 8192:  launch_b<float, 8>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
-        case 16384: launch_b<float, 16>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
+        case 256:   launch_b<float, 8, true>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
+        case 512:   launch_b<float, 16, true>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
+        case 1024:  launch_b<float, 32, true>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
+        case 2048:  launch_b<float, 2, false>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
+        case 4096:  launch_b<float, 4, false>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
+        case 8192:  launch_b<float, 8, false>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
+        case 16384: launch_b<float, 16, false>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
         default:
-            if (inverse) launch_one<float, 32, DSC_MODE_C2C, true>(in, out, n_lines, tw_full, tw_real, scale, stream);
-            else         launch_one<float, 32, DSC_MODE_C2C, false>(in, out, n_lines, tw_full, tw_real, scale, stream);
+            if (inverse) launch_one<float, 32, false, DSC_MODE_C2C, true>(in, out, n_lines, tw_full, tw_real, scale, stream);
+            else         launch_one<float, 32, false, DSC_MODE_C2C, false>(in, out, n_lines, tw_full, tw_real, scale, stream);
             break;
     }
 }

@@ -193,14 +193,14 @@ def test_f64_262144_register_path(dsc):
         assert rel_l2(bh, x) <= 1e-14
 
 
-@pytest.mark.parametrize('n', [4096, 8192, 16384, 32768])
+@pytest.mark.parametrize('n', [512, 1024, 2048, 4096, 8192, 16384, 32768])
 def test_mid_size_register_path(dsc, n):
-    """Real lengths 4096 .. 32768 (complex 2048 .. 16384) of contiguous full rows run in
+    """Real lengths 512 .. 32768 (complex 256 .. 16384) of contiguous full rows run in
     fft_regs_mid.hip; row counts that are not a multiple of the lines-per-workgroup exercise
     the partially filled last group.  rfft / irfft / fft / ifft against the oracle."""
     from oracle import port
     rng = np.random.default_rng(n)
-    for rows in (1, 5, 67):
+    for rows in (1, 5, 67, 131):
         x = rng.standard_normal((rows, n)).astype(np.float32)
         X = dsc.rfft(dsc.from_numpy(x))
         assert dsc.last_fft_path() == 'regs_mid'

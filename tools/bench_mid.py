@@ -7,7 +7,7 @@ import dsc_amd as dsc
 from dsc_amd import _bindings as B
 from dsc_amd.context import _get_ctx
 
-sizes = [int(a) for a in sys.argv[1:]] or [4096, 8192, 16384, 32768, 65536]
+sizes = [int(a) for a in sys.argv[1:]] or [512, 1024, 2048, 4096, 8192, 16384, 32768, 65536]
 dsc.init(16 << 30, 2 << 30)
 ctx = _get_ctx()
 
