@@ -290,7 +290,7 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
         const int x_n = j.x->shape[j.slot];
         const int want = j.mode == DSC_MODE_R2C_PACKED ? 2 * j.L : j.mode == DSC_MODE_C2R_PACKED ? j.L + 1 : j.L;
         if (j.in_len == want && x_n == want) {
-            dsc_launch_fft_regs_mid(j.x->data, j.out->data, n_lines, j.L, j.mode, j.inverse, plan->tw_full, plan->tw_real, j.scale,
+            dsc_launch_fft_regs_mid(j.x->data, j.out->data, n_lines, j.L, j.mode, j.inverse, sp, plan->tw_full, plan->tw_real, j.scale,
                                     ctx->stream);
             ctx->last_fft_path = "regs_mid";
             return;

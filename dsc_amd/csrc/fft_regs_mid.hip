@@ -1,6 +1,7 @@
 // fft_regs_mid.hip — register-resident transforms of contiguous lines with complex length
 // L = 1024 B, B in {2, 4, 8, 16}  (real lengths 4096 .. 32768, complex 2048 .. 16384) and, for
 // complex data, B = 32 (L = 32768), f32.
+// The same kernels in f64 for L = 256 .. 16384.
 //
 // The design of fft_r2c_64k.hip / fft_r2c_256k_f64.hip, parameterised by B: a line lives in
 // the registers of T = 32 B threads, 32 complex each; G = 16/B (or 8/B) lines share a
@@ -113,13 +114,18 @@ __device__ __forceinline__ void lds_barrier() {
 
 // TWO = false: L = 1024 B, three passes (32 x 32 x B), T = 32 B threads per line.
 // TWO = true:  L = 32 B,   two passes  (32 x B),       T = B threads per line (a wave holds 64 / B lines).
-template<int B, bool TWO> struct mid_cfg {
+template<typename R, int B, bool TWO> struct mid_cfg {
+    static constexpr bool DP = sizeof(R) == 8;
     static constexpr int T = TWO ? B : 32 * B;       // threads per line
     static constexpr int L = 32 * T;                 // complex length
     static constexpr int COLS = TWO ? 32 : 1024;     // columns entering the last pass (DFT_B down each)
-    static constexpr int NT = TWO ? 256 : B >= 32 ? 1024 : B >= 8 ? 512 : 256;
+    // threads per workgroup.  f32: a thread needs ~100 VGPRs and 132-264 B of LDS, so two 512-thread groups (or three
+    // of 256) share a CU and overlap each other's load / compute / store phases.  f64: twice the registers (one
+    // 512-thread group or several smaller ones per CU) and twice the LDS, which decides the group size.
+    static constexpr int NT = DP ? (TWO ? (B >= 32 ? 128 : 256) : (B >= 8 ? 512 : 128))
+                                 : (TWO ? 256 : B >= 32 ? 1024 : B >= 8 ? 512 : 256);
     static constexpr int G = NT / T;                 // lines per workgroup
-    static constexpr int WAVES_PER_EU = TWO ? 2 : B >= 8 ? 4 : 2;   // VGPR budget: <= 128 where two 512-thread groups share a CU
+    static constexpr int WAVES_PER_EU = DP ? 2 : (TWO ? 2 : B >= 8 ? 4 : 2);   // f32: <= 128 VGPRs where two 512-thread groups share a CU
     static constexpr int P1 = 33;                    // exchange-1 row pitch (values): odd
     static constexpr int P2 = B + 1;                 // last-exchange row pitch
     static constexpr int SP = L + 1;                 // staging pitch per line (bins 0 .. L)
@@ -130,7 +136,7 @@ template<int B, bool TWO> struct mid_cfg {
 };
 
 template<typename R, int B, bool TWO>
-constexpr size_t mid_lds_bytes() { return ((size_t) mid_cfg<B, TWO>::PLANE + 2 * mid_cfg<B, TWO>::TABLE) * sizeof(R); }
+constexpr size_t mid_lds_bytes() { return ((size_t) mid_cfg<R, B, TWO>::PLANE + 2 * mid_cfg<R, B, TWO>::TABLE) * sizeof(R); }
 
 typedef unsigned int u2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
@@ -157,11 +163,11 @@ __device__ __forceinline__ void buf_store(cpx<double> a, __amdgpu_buffer_rsrc_t 
 
 // MODE: DSC_MODE_C2C, DSC_MODE_R2C_PACKED (forward only), DSC_MODE_C2R_PACKED (inverse only)
 template<typename R, int B, bool TWO, int MODE, bool INV>
-__global__ __launch_bounds__((mid_cfg<B, TWO>::NT), (mid_cfg<B, TWO>::WAVES_PER_EU)) void fft_mid_kernel(
+__global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVES_PER_EU)) void fft_mid_kernel(
     const cpx<R> *__restrict__ in, cpx<R> *__restrict__ out, long long n_lines, const cpx<R> *__restrict__ tw_full,
     const cpx<R> *__restrict__ tw_real, R scale) {
     using C = cpx<R>;
-    using cfg = mid_cfg<B, TWO>;
+    using cfg = mid_cfg<R, B, TWO>;
     constexpr int T = cfg::T, L = cfg::L, G = cfg::G, NT = cfg::NT, P1 = cfg::P1, P2 = cfg::P2, SP = cfg::SP, CPT = cfg::CPT;
     constexpr int COLS = cfg::COLS;
     constexpr int LOGB = ilog2(B);
@@ -353,7 +359,7 @@ __global__ __launch_bounds__((mid_cfg<B, TWO>::NT), (mid_cfg<B, TWO>::WAVES_PER_
 
 template<typename R, int B, bool TWO, int MODE, bool INV>
 void launch_one(const void *in, void *out, long long n_lines, const void *tw_full, const void *tw_real, double scale, hipStream_t stream) {
-    using cfg = mid_cfg<B, TWO>;
+    using cfg = mid_cfg<R, B, TWO>;
     constexpr size_t lds = mid_lds_bytes<R, B, TWO>();
     static bool attr_set = false;
     if (!attr_set) {
@@ -377,26 +383,34 @@ void launch_b(const void *in, void *out, long long n_lines, dsc_fft_mode mode, b
 }  // namespace
 
 bool dsc_fft_regs_mid_supports(int L, dsc_fft_mode mode, bool single_precision) {
-    if (!single_precision) return false;
     if (mode == DSC_MODE_R2C_CAST) return false;
-    if (L == 32768) return mode == DSC_MODE_C2C;          // the packed-real 65536-point transforms have their own kernels
+    if (L == 32768) return single_precision && mode == DSC_MODE_C2C;   // the packed-real 65536-point f32 transforms have their own kernels
     return L == 256 || L == 512 || L == 1024 || L == 2048 || L == 4096 || L == 8192 || L == 16384;
 }
 
-void dsc_launch_fft_regs_mid(const void *in, void *out, long long n_lines, int L, dsc_fft_mode mode, bool inverse, const void *tw_full,
-                             const void *tw_real, double scale, hipStream_t stream) {
-    if (n_lines <= 0) return;
+template<typename R>
+static void launch_len(const void *in, void *out, long long n_lines, int L, dsc_fft_mode mode, bool inverse, const void *tw_full,
+                       const void *tw_real, double scale, hipStream_t stream) {
     switch (L) {
-        case 256:   launch_b<float, 8, true>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
-        case 512:   launch_b<float, 16, true>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
-        case 1024:  launch_b<float, 32, true>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
-        case 2048:  launch_b<float, 2, false>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
-        case 4096:  launch_b<float, 4, false>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
-        case 8192:  launch_b<float, 8, false>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
-        case 16384: launch_b<float, 16, false>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
-        default:
-            if (inverse) launch_one<float, 32, false, DSC_MODE_C2C, true>(in, out, n_lines, tw_full, tw_real, scale, stream);
-            else         launch_one<float, 32, false, DSC_MODE_C2C, false>(in, out, n_lines, tw_full, tw_real, scale, stream);
-            break;
+        case 256:   launch_b<R, 8, true>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
+        case 512:   launch_b<R, 16, true>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
+        case 1024:  launch_b<R, 32, true>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
+        case 2048:  launch_b<R, 2, false>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
+        case 4096:  launch_b<R, 4, false>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
+        case 8192:  launch_b<R, 8, false>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
+        default:    launch_b<R, 16, false>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
+    }
+}
+
+void dsc_launch_fft_regs_mid(const void *in, void *out, long long n_lines, int L, dsc_fft_mode mode, bool inverse, bool single_precision,
+                             const void *tw_full, const void *tw_real, double scale, hipStream_t stream) {
+    if (n_lines <= 0) return;
+    if (!single_precision) {
+        launch_len<double>(in, out, n_lines, L, mode, inverse, tw_full, tw_real, scale, stream);
+    } else if (L == 32768) {
+        if (inverse) launch_one<float, 32, false, DSC_MODE_C2C, true>(in, out, n_lines, tw_full, tw_real, scale, stream);
+        else         launch_one<float, 32, false, DSC_MODE_C2C, false>(in, out, n_lines, tw_full, tw_real, scale, stream);
+    } else {
+        launch_len<float>(in, out, n_lines, L, mode, inverse, tw_full, tw_real, scale, stream);
     }
 }

@@ -82,12 +82,12 @@ void   dsc_launch_rfft256k_f64(const double *x, void *X, long long rows, void *w
 void   dsc_launch_irfft256k_f64(const void *X, double *x, long long rows, void *work, const void *aux, const void *tw_real,
                                 int n_cu, hipStream_t stream);
 
-// ---- register-resident transforms of contiguous full lines, complex length 2048 .. 16384 (f32) -------
+// ---- register-resident transforms of contiguous full lines, complex length 256 .. 16384 (f32, f64; f32 C2C also 32768)
 // (fft_regs_mid.hip).  in / out: [n_lines][L] complex (C2C), [n_lines][2L] reals -> [n_lines][L+1] bins
 // (R2C_PACKED) or the converse (C2R_PACKED).  tw_full: W_L^k, k < L; tw_real: W_{2L}^k, k <= L.
 bool dsc_fft_regs_mid_supports(int L, dsc_fft_mode mode, bool single_precision);
-void dsc_launch_fft_regs_mid(const void *in, void *out, long long n_lines, int L, dsc_fft_mode mode, bool inverse, const void *tw_full,
-                             const void *tw_real, double scale, hipStream_t stream);
+void dsc_launch_fft_regs_mid(const void *in, void *out, long long n_lines, int L, dsc_fft_mode mode, bool inverse, bool single_precision,
+                             const void *tw_full, const void *tw_real, double scale, hipStream_t stream);
 
 // ---- element-wise ------------------------------------------------------------------------
 // dtype codes are dsc_dtype values (0 f32, 1 f64, 2 c32, 3 c64)

@@ -229,3 +229,35 @@ def test_mid_size_register_path(dsc, n):
         assert dsc.last_fft_path() == 'regs_mid'
         assert_close(zb.numpy()[0], port.ifft(zh[0]), what=f'ifft n={n // 2}')
         assert rel_l2(zb.numpy(), z) <= 1e-6
+
+
+@pytest.mark.parametrize('n', [512, 1024, 2048, 4096, 8192, 16384, 32768])
+def test_mid_size_register_path_f64(dsc, n):
+    """The same kernels in f64 (tolerance 1e-12 against the oracle)."""
+    from oracle import port
+    rng = np.random.default_rng(n + 1)
+    for rows in (1, 37):
+        x = rng.standard_normal((rows, n))
+        X = dsc.rfft(dsc.from_numpy(x))
+        assert dsc.last_fft_path() == 'regs_mid'
+        got = X.numpy()
+        for r in sorted({0, rows - 1}):
+            assert_close(got[r], port.rfft(x[r]), what=f'f64 rfft n={n} row {r}/{rows}')
+        assert rel_l2(got, np.fft.rfft(x, axis=-1)) <= 1e-14
+        assert np.all(got[:, 0].imag == 0) and np.all(got[:, -1].imag == 0)
+        Xq = got.copy()
+        Xq[:, 0] += 2j
+        Xq[:, -1] -= 3j
+        back = dsc.irfft(dsc.from_numpy(Xq))
+        assert dsc.last_fft_path() == 'regs_mid'
+        bh = back.numpy()
+        assert_close(bh[rows - 1], port.irfft(Xq[rows - 1]), what=f'f64 irfft n={n}')
+        assert rel_l2(bh, x) <= 1e-14
+        z = rng.standard_normal((rows, n // 2)) + 1j * rng.standard_normal((rows, n // 2))
+        Z = dsc.fft(dsc.from_numpy(z))
+        assert dsc.last_fft_path() == 'regs_mid'
+        zh = Z.numpy()
+        assert_close(zh[rows - 1], port.fft(z[rows - 1]), what=f'f64 fft n={n // 2}')
+        zb = dsc.ifft(Z)
+        assert dsc.last_fft_path() == 'regs_mid'
+        assert rel_l2(zb.numpy(), z) <= 1e-14

@@ -7,7 +7,8 @@ import dsc_amd as dsc
 from dsc_amd import _bindings as B
 from dsc_amd.context import _get_ctx
 
-sizes = [int(a) for a in sys.argv[1:]] or [512, 1024, 2048, 4096, 8192, 16384, 32768, 65536]
+f64 = '--f64' in sys.argv
+sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [512, 1024, 2048, 4096, 8192, 16384, 32768, 65536]
 dsc.init(16 << 30, 2 << 30)
 ctx = _get_ctx()
 
@@ -27,19 +28,20 @@ def timeit(f, reps=20, warm=10, rounds=3):
 
 
 for n in sizes:
-    b = (1 << 29) // n
-    x = dsc.from_numpy(np.random.default_rng(0).standard_normal((b, n)).astype(np.float32))
-    X = dsc.empty((b, n // 2 + 1), dsc.Dtype.C32)
+    b = (1 << (28 if f64 else 29)) // n
+    rdt, cdt, esz, nm = (np.float64, dsc.Dtype.C64, 8, 'f64') if f64 else (np.float32, dsc.Dtype.C32, 4, 'f32')
+    x = dsc.from_numpy(np.random.default_rng(0).standard_normal((b, n)).astype(rdt))
+    X = dsc.empty((b, n // 2 + 1), cdt)
     ms = timeit(lambda: B.dsc_rfft(ctx, x._c_ptr, X._c_ptr, -1, -1))
     path = dsc.last_fft_path()
-    nb = b * (n * 4 + (n // 2 + 1) * 8)
-    print(f'rfft  f32 N={n:6d} B={b:6d}: {ms:7.3f} ms  {nb / ms / 1e9:6.3f} TB/s  {100 * nb / ms / 8e9:5.1f}% of 8 TB/s  [{path}]', flush=True)
+    nb = b * (n * esz + (n // 2 + 1) * 2 * esz)
+    print(f'rfft  {nm} N={n:6d} B={b:6d}: {ms:7.3f} ms  {nb / ms / 1e9:6.3f} TB/s  {100 * nb / ms / 8e9:5.1f}% of 8 TB/s  [{path}]', flush=True)
     ms = timeit(lambda: B.dsc_irfft(ctx, X._c_ptr, x._c_ptr, -1, -1))
-    print(f'irfft f32 N={n:6d} B={b:6d}: {ms:7.3f} ms  {nb / ms / 1e9:6.3f} TB/s  {100 * nb / ms / 8e9:5.1f}% of 8 TB/s  [{dsc.last_fft_path()}]', flush=True)
+    print(f'irfft {nm} N={n:6d} B={b:6d}: {ms:7.3f} ms  {nb / ms / 1e9:6.3f} TB/s  {100 * nb / ms / 8e9:5.1f}% of 8 TB/s  [{dsc.last_fft_path()}]', flush=True)
     del x, X
-    z = dsc.empty((b, n // 2), dsc.Dtype.C32)
-    Z = dsc.empty((b, n // 2), dsc.Dtype.C32)
+    z = dsc.empty((b, n // 2), cdt)
+    Z = dsc.empty((b, n // 2), cdt)
     ms = timeit(lambda: B.dsc_fft(ctx, z._c_ptr, Z._c_ptr, -1, -1))
-    nb = b * n * 8
-    print(f'fft   c32 L={n // 2:6d} B={b:6d}: {ms:7.3f} ms  {nb / ms / 1e9:6.3f} TB/s  {100 * nb / ms / 8e9:5.1f}% of 8 TB/s  [{dsc.last_fft_path()}]', flush=True)
+    nb = b * n * 2 * esz
+    print(f'fft   c{nm[1:]} L={n // 2:6d} B={b:6d}: {ms:7.3f} ms  {nb / ms / 1e9:6.3f} TB/s  {100 * nb / ms / 8e9:5.1f}% of 8 TB/s  [{dsc.last_fft_path()}]', flush=True)
     del z, Z
