@@ -154,6 +154,13 @@ __device__ __forceinline__ cpx<double> buf_load(__amdgpu_buffer_rsrc_t r, int vo
     const d2 q = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
     return cpx<double>{q.x, q.y};
 }
+// real sample widened to complex (dsc_fft on real input casts first: dsc.cpp:1984-1988)
+__device__ __forceinline__ cpx<float> buf_load_real(__amdgpu_buffer_rsrc_t r, int voff, int soff, float) {
+    return cpx<float>{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0)), 0.0f};
+}
+__device__ __forceinline__ cpx<double> buf_load_real(__amdgpu_buffer_rsrc_t r, int voff, int soff, double) {
+    return cpx<double>{__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0)), 0.0};
+}
 __device__ __forceinline__ void buf_store(cpx<float> a, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, f2{a.x, a.y}), r, voff, soff, 0);
 }
@@ -161,7 +168,7 @@ __device__ __forceinline__ void buf_store(cpx<double> a, __amdgpu_buffer_rsrc_t 
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, d2{a.x, a.y}), r, voff, soff, 0);
 }
 
-// MODE: DSC_MODE_C2C, DSC_MODE_R2C_PACKED (forward only), DSC_MODE_C2R_PACKED (inverse only)
+// MODE: DSC_MODE_C2C, DSC_MODE_R2C_CAST (L reals in), DSC_MODE_R2C_PACKED (forward only), DSC_MODE_C2R_PACKED (inverse only)
 template<typename R, int B, bool TWO, int MODE, bool INV>
 __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVES_PER_EU)) void fft_mid_kernel(
     const cpx<R> *__restrict__ in, cpx<R> *__restrict__ out, long long n_lines, const cpx<R> *__restrict__ tw_full,
@@ -185,9 +192,11 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
     const int hi = TWO ? 0 : t / B, lo = TWO ? t : t % B;
     constexpr int in_pitch = MODE == DSC_MODE_C2R_PACKED ? L + 1 : L;
     constexpr int out_pitch = MODE == DSC_MODE_R2C_PACKED ? L + 1 : L;
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *) (in + line0 * in_pitch), 0, n_valid * in_pitch * CB, 0x00020000);
+    constexpr int IB = MODE == DSC_MODE_R2C_CAST ? (int) sizeof(R) : CB;      // bytes per input element
+    const __amdgpu_buffer_rsrc_t rin =
+        __builtin_amdgcn_make_buffer_rsrc((void *) ((const char *) in + line0 * in_pitch * IB), 0, n_valid * in_pitch * IB, 0x00020000);
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *) (out + line0 * out_pitch), 0, n_valid * out_pitch * CB, 0x00020000);
-    const int vin = (g * in_pitch + t) * CB;                       // byte offset of element t of this thread's line
+    const int vin = (g * in_pitch + t) * IB;                       // byte offset of element t of this thread's line
     const int vout = (g * out_pitch + t) * CB;
     R *stage = plane + g * SP;
 
@@ -195,7 +204,10 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
 
     C v[32];
 #pragma unroll
-    for (int j1 = 0; j1 < 32; ++j1) v[j1] = buf_load(rin, vin, j1 * T * CB, R{});             // z[T j1 + t]
+    for (int j1 = 0; j1 < 32; ++j1) {                                                        // z[T j1 + t]
+        if constexpr (MODE == DSC_MODE_R2C_CAST) v[j1] = buf_load_real(rin, vin, j1 * T * IB, R{});
+        else                                     v[j1] = buf_load(rin, vin, j1 * T * CB, R{});
+    }
 
     if constexpr (MODE == DSC_MODE_C2R_PACKED) {
         // Z[k] = (a + conj b)/2 + wq (a - conj b), a = Y[k], b = Y[L-k], wq = (i/2) conj(W_2L^k), for the
@@ -376,6 +388,8 @@ void launch_b(const void *in, void *out, long long n_lines, dsc_fft_mode mode, b
               double scale, hipStream_t stream) {
     if (mode == DSC_MODE_R2C_PACKED)      launch_one<R, B, TWO, DSC_MODE_R2C_PACKED, false>(in, out, n_lines, tw_full, tw_real, scale, stream);
     else if (mode == DSC_MODE_C2R_PACKED) launch_one<R, B, TWO, DSC_MODE_C2R_PACKED, true>(in, out, n_lines, tw_full, tw_real, scale, stream);
+    else if (mode == DSC_MODE_R2C_CAST && !inverse) launch_one<R, B, TWO, DSC_MODE_R2C_CAST, false>(in, out, n_lines, tw_full, tw_real, scale, stream);
+    else if (mode == DSC_MODE_R2C_CAST)   launch_one<R, B, TWO, DSC_MODE_R2C_CAST, true>(in, out, n_lines, tw_full, tw_real, scale, stream);
     else if (inverse)                     launch_one<R, B, TWO, DSC_MODE_C2C, true>(in, out, n_lines, tw_full, tw_real, scale, stream);
     else                                  launch_one<R, B, TWO, DSC_MODE_C2C, false>(in, out, n_lines, tw_full, tw_real, scale, stream);
 }
@@ -383,7 +397,6 @@ void launch_b(const void *in, void *out, long long n_lines, dsc_fft_mode mode, b
 }  // namespace
 
 bool dsc_fft_regs_mid_supports(int L, dsc_fft_mode mode, bool single_precision) {
-    if (mode == DSC_MODE_R2C_CAST) return false;
     if (L == 32768) return single_precision && mode == DSC_MODE_C2C;   // the packed-real 65536-point f32 transforms have their own kernels
     return L == 256 || L == 512 || L == 1024 || L == 2048 || L == 4096 || L == 8192 || L == 16384;
 }

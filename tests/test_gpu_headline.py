@@ -229,6 +229,14 @@ def test_mid_size_register_path(dsc, n):
         assert dsc.last_fft_path() == 'regs_mid'
         assert_close(zb.numpy()[0], port.ifft(zh[0]), what=f'ifft n={n // 2}')
         assert rel_l2(zb.numpy(), z) <= 1e-6
+        # complex transform of REAL input (cast first: dsc.cpp:1984-1988), forward and inverse
+        xr = x[:, :n // 2].copy()
+        F = dsc.fft(dsc.from_numpy(xr))
+        assert dsc.last_fft_path() == 'regs_mid'
+        assert_close(F.numpy()[rows - 1], port.fft(xr[rows - 1]), what=f'fft(real) n={n // 2}')
+        Fi = dsc.ifft(dsc.from_numpy(xr))
+        assert dsc.last_fft_path() == 'regs_mid'
+        assert_close(Fi.numpy()[0], port.ifft(xr[0]), what=f'ifft(real) n={n // 2}')
 
 
 @pytest.mark.parametrize('n', [512, 1024, 2048, 4096, 8192, 16384, 32768])
