@@ -7,7 +7,10 @@
 //
 //   r2c_64k_regs / c2r_64k_regs   f32, 65536-point real transform of contiguous rows:
 //                                  register-resident, one HBM round trip (fft_r2c_64k.hip)
-//   generic_lds                    complex length <= dsc_fft_lds_max_len: one pass (fft_generic.hip)
+//   r2c_256k_f64_regs / c2r_...    f64, 262144-point real transform: three passes (fft_r2c_256k_f64.hip)
+//   regs_mid                       contiguous full lines, complex length 256 .. 16384 (f32, f64; f32 complex
+//                                  also 32768): register-resident, one HBM round trip (fft_regs_mid.hip)
+//   generic_lds                    any axis / padding, complex length <= dsc_fft_lds_max_len: one pass (fft_generic.hip)
 //   generic_4step                  longer: pack -> columns(+twiddle) -> rows -> post/unpack,
 //                                  chunked over lines to fit the scratch arena
 #include "dsc_internal.h"
@@ -269,6 +272,17 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
             ctx->scratch.reset();
             long long chunk = (long long) ((ctx->scratch.capacity() - DSC_DEVICE_ALIGN) / row_bytes);
             if (chunk < 1) DSC_LOG_FATAL("scratch arena too small: a 262144-point f64 transform needs 2 MB of scratch per row");
+            {
+                // Keep the work buffer of a chunk inside the 256 MiB Infinity Cache: the three passes then exchange it
+                // on-die and only the input and the output rows travel over HBM.
+                static long long cap_rows = -1;
+                if (cap_rows < 0) {
+                    const char *e = getenv("DSC_C5_CHUNK_ROWS");
+                    cap_rows = e ? atoll(e) : 64;
+                    if (cap_rows < 1) cap_rows = 1;
+                }
+                if (chunk > cap_rows) chunk = cap_rows;
+            }
             if (chunk > n_lines) chunk = n_lines;
             char *work = ctx->scratch.alloc((size_t) chunk * row_bytes);
             for (long long q = 0; q < n_lines; q += chunk) {
@@ -286,7 +300,8 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
     }
 
     // register-resident mid sizes: contiguous full lines along the last axis
-    if (inner == 1 && dsc_fft_regs_mid_supports(j.L, j.mode, sp) && !getenv("DSC_NO_REGS_MID")) {
+    static const bool regs_mid_off = getenv("DSC_NO_REGS_MID") != nullptr;      // A/B aid (tools/bench_mid.py)
+    if (inner == 1 && !regs_mid_off && dsc_fft_regs_mid_supports(j.L, j.mode, sp)) {
         const int x_n = j.x->shape[j.slot];
         const int want = j.mode == DSC_MODE_R2C_PACKED ? 2 * j.L : j.mode == DSC_MODE_C2R_PACKED ? j.L + 1 : j.L;
         if (j.in_len == want && x_n == want) {
