@@ -91,6 +91,37 @@ dsc_fft = _sig('dsc_fft', _DscTensor_p, _DscCtx, _DscTensor_p, _DscTensor_p, c_i
 dsc_ifft = _sig('dsc_ifft', _DscTensor_p, _DscCtx, _DscTensor_p, _DscTensor_p, c_int, c_int)
 dsc_rfft = _sig('dsc_rfft', _DscTensor_p, _DscCtx, _DscTensor_p, _DscTensor_p, c_int, c_int)
 dsc_irfft = _sig('dsc_irfft', _DscTensor_p, _DscCtx, _DscTensor_p, _DscTensor_p, c_int, c_int)
+
+
+class _DscSlice(Structure):            # dsc.h:110-117, python/dsc/_bindings.py:72-73
+    _fields_ = [('start', c_int), ('stop', c_int), ('step', c_int)]
+
+
+DSC_VALUE_NONE = 2 ** 31 - 1           # dsc.h:78
+
+# variadic (dsc.h:244-260): only the fixed arguments are typed, as python/dsc/_bindings.py:413-459
+_dsc_tensor_get_idx = _sig('dsc_tensor_get_idx', _DscTensor_p, _DscCtx, _DscTensor_p, c_int)
+_dsc_tensor_get_slice = _sig('dsc_tensor_get_slice', _DscTensor_p, _DscCtx, _DscTensor_p, c_int)
+_dsc_tensor_set_idx = _sig('dsc_tensor_set_idx', None, _DscCtx, _DscTensor_p, _DscTensor_p, c_int)
+_dsc_tensor_set_slice = _sig('dsc_tensor_set_slice', None, _DscCtx, _DscTensor_p, _DscTensor_p, c_int)
+
+
+def dsc_tensor_get_idx(ctx, x, *indexes):
+    return _dsc_tensor_get_idx(ctx, x, len(indexes), *[c_int(i) for i in indexes])
+
+
+def dsc_tensor_get_slice(ctx, x, *slices):
+    return _dsc_tensor_get_slice(ctx, x, len(slices), *slices)
+
+
+def dsc_tensor_set_idx(ctx, xa, xb, *indexes):
+    _dsc_tensor_set_idx(ctx, xa, xb, len(indexes), *[c_int(i) for i in indexes])
+
+
+def dsc_tensor_set_slice(ctx, xa, xb, *slices):
+    _dsc_tensor_set_slice(ctx, xa, xb, len(slices), *slices)
+
+
 dsc_set_device = _sig('dsc_set_device', c_int, c_int)
 dsc_copy_from_host = _sig('dsc_copy_from_host', None, _DscCtx, _DscTensor_p, c_void_p, c_size_t)
 dsc_copy_to_host = _sig('dsc_copy_to_host', None, _DscCtx, _DscTensor_p, c_void_p, c_size_t)
@@ -101,4 +132,4 @@ dsc_timer_stop = _sig('dsc_timer_stop', c_float, _DscCtx)
 dsc_filter_fft = _sig('dsc_filter_fft', _DscTensor_p, _DscCtx, _DscTensor_p, _DscTensor_p, _DscTensor_p)
 dsc_last_fft_path = _sig('dsc_last_fft_path', c_char_p, _DscCtx)
 
-EXPORTS = [n for n in dir() if n.startswith('dsc_')]
+EXPORTS = [n for n in dir() if n.startswith('dsc_') and n != 'dsc_api']

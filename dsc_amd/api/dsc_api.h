@@ -2,7 +2,7 @@
 //
 // Mirror of the reference's dsc/api/dsc_api.h for the hot-path subset: `dsc::init`, RAII
 // `dsc::tensor<T>`, `operator*`, `dsc::sum`, `dsc::fft / ifft / rfft / irfft` (reference
-// lines 24-34, 36-110, 165-173, 285-290, 321-343) plus `dsc::filter_fft`.  The one semantic
+// lines 15-21, 24-34, 36-143, 165-173, 285-290, 321-343) plus `dsc::filter_fft`.  The one semantic
 // difference: tensor payloads live in HBM, so construction from host data and `to_host()`
 // copy through dsc_copy_from_host / dsc_copy_to_host instead of dereferencing `data()`
 // (reference: memcpy into x_->data, dsc_api.h:63-66).
@@ -12,7 +12,16 @@
 
 #include <cstddef>
 #include <initializer_list>
+#include <type_traits>
 #include <vector>
+
+// dsc_api.h:15-21
+#define DSC_SLICE_ALL()                 (dsc_slice{DSC_VALUE_NONE, DSC_VALUE_NONE, 1})
+#define DSC_SLICE_IDX(idx_)             (dsc_slice{(idx_), (idx_), (idx_)})      // a single element, not a slice
+#define DSC_SLICE_ALL_STEP(step_)       (dsc_slice{DSC_VALUE_NONE, DSC_VALUE_NONE, (step_)})
+#define DSC_SLICE_FROM(start_)          (dsc_slice{(start_), DSC_VALUE_NONE, 1})
+#define DSC_SLICE_TO(stop_)             (dsc_slice{DSC_VALUE_NONE, (stop_), 1})
+#define DSC_SLICE_RANGE(start_, stop_)  (dsc_slice{(start_), (stop_), 1})
 
 namespace dsc {
 
@@ -85,6 +94,19 @@ public:
     }
 
     tensor operator*(const tensor &other) const noexcept { return dsc_mul(ctx, x_, other.x_, nullptr); }   // dsc_api.h:165-173
+
+    // dsc_api.h:117-143: x.get(2, 3) (indexes) / x.get(DSC_SLICE_ALL(), DSC_SLICE_TO(n)) (slices) copy on the device
+    template<typename... Args>
+    tensor get(Args... sel) const noexcept {
+        if constexpr ((std::is_same_v<Args, dsc_slice> && ...)) return dsc_tensor_get_slice(ctx, x_, (int) sizeof...(Args), sel...);
+        else                                                      return dsc_tensor_get_idx(ctx, x_, (int) sizeof...(Args), ((int) sel)...);
+    }
+    template<typename... Args>
+    tensor &set(const tensor &other, Args... sel) noexcept {
+        if constexpr ((std::is_same_v<Args, dsc_slice> && ...)) dsc_tensor_set_slice(ctx, x_, other.x_, (int) sizeof...(Args), sel...);
+        else                                                      dsc_tensor_set_idx(ctx, x_, other.x_, (int) sizeof...(Args), ((int) sel)...);
+        return *this;
+    }
 
     dsc_tensor *x_;
 };

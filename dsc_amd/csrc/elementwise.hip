@@ -203,3 +203,69 @@ void dsc_launch_binary(const void *a, const void *b, void *out, int dtype, int o
         default: binary_typed<cx<double>>(a, b, out, op, g, grid, stream); break;
     }
 }
+
+// ---- slice regions: dsc_tensor_get_slice / set_slice (dsc.cpp:868-1169) ---------------------
+// The reference walks a dsc_slice_iterator (dsc_iter.h:125-190) per element; here a block owns a piece of
+// one innermost row of the region (one division chain per block), or — for narrow rows — a flat
+// per-element decomposition.
+namespace {
+
+struct alignas(16) b16 { unsigned long long a, b; };
+
+template<typename E, bool SCATTER>
+__global__ void region_rows_kernel(const E *src, E *dst, const dsc_region r, unsigned chunks_per_row, long long dense_ne) {
+    const unsigned long long blk = blockIdx.x;
+    const unsigned long long row = blk / chunks_per_row;
+    const unsigned chunk = (unsigned) (blk - row * chunks_per_row);
+    const unsigned long long i01 = row / r.count[2];
+    const long long i2 = (long long) (row - i01 * r.count[2]);
+    const long long i0 = (long long) (i01 / r.count[1]), i1 = (long long) (i01 - (unsigned long long) i0 * r.count[1]);
+    const long long base = r.base + i0 * r.stride[0] + i1 * r.stride[1] + i2 * r.stride[2];
+    const long long dense0 = (long long) row * r.count[3];
+    const int c = chunk * blockDim.x + threadIdx.x;
+    if (c >= r.count[3]) return;
+    if (SCATTER) dst[base + c * r.stride[3]] = src[(dense0 + c) % dense_ne];
+    else         dst[dense0 + c] = src[base + c * r.stride[3]];
+}
+
+template<typename E, bool SCATTER>
+__global__ void region_flat_kernel(const E *src, E *dst, const dsc_region r, long long dense_ne) {
+    const long long s3 = r.count[3], s23 = s3 * r.count[2], s123 = s23 * r.count[1];
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < r.ne; i += (long long) gridDim.x * blockDim.x) {
+        const long long i0 = i / s123, r0 = i - i0 * s123;
+        const long long i1 = r0 / s23, r1 = r0 - i1 * s23;
+        const long long i2 = r1 / s3, i3 = r1 - i2 * s3;
+        const long long at = r.base + i0 * r.stride[0] + i1 * r.stride[1] + i2 * r.stride[2] + i3 * r.stride[3];
+        if (SCATTER) dst[at] = src[i % dense_ne];
+        else         dst[i] = src[at];
+    }
+}
+
+template<typename E>
+void region_typed(const void *src, void *dst, const dsc_region &r, bool scatter, long long dense_ne, hipStream_t s) {
+    const E *ps = (const E *) src;
+    E *pd = (E *) dst;
+    const long long rows = r.ne / r.count[3];
+    if (r.count[3] >= 128 && rows * ((r.count[3] + 255) / 256) < (1LL << 31)) {
+        const unsigned chunks = (unsigned) ((r.count[3] + 255) / 256);
+        const dim3 grid((unsigned) (rows * chunks));
+        if (scatter) hipLaunchKernelGGL((region_rows_kernel<E, true>), grid, dim3(256), 0, s, ps, pd, r, chunks, dense_ne);
+        else         hipLaunchKernelGGL((region_rows_kernel<E, false>), grid, dim3(256), 0, s, ps, pd, r, chunks, dense_ne);
+    } else {
+        const dim3 grid = stream_grid(r.ne);
+        if (scatter) hipLaunchKernelGGL((region_flat_kernel<E, true>), grid, dim3(256), 0, s, ps, pd, r, dense_ne);
+        else         hipLaunchKernelGGL((region_flat_kernel<E, false>), grid, dim3(256), 0, s, ps, pd, r, dense_ne);
+    }
+}
+
+}  // namespace
+
+void dsc_launch_region_copy(const void *src, void *dst, int elem_bytes, const dsc_region &r, bool scatter, long long dense_ne,
+                            hipStream_t stream) {
+    if (r.ne <= 0) return;
+    switch (elem_bytes) {
+        case 4:  region_typed<unsigned int>(src, dst, r, scatter, dense_ne, stream); break;
+        case 8:  region_typed<unsigned long long>(src, dst, r, scatter, dense_ne, stream); break;
+        default: region_typed<b16>(src, dst, r, scatter, dense_ne, stream); break;
+    }
+}

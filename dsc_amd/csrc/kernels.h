@@ -116,3 +116,16 @@ void dsc_launch_binary(const void *a, const void *b, void *out, int dtype, int o
 // workspace: scratch for the segmented path (may be NULL)
 void dsc_launch_reduce(const void *x, void *out, int dtype, int op, long long outer, int axis_n, long long inner,
                        void *workspace, size_t workspace_bytes, hipStream_t stream);
+
+// ---- strided gather / scatter of a slice region (indexing.cpp) -----------------------------
+// Region of a tensor: element (i0, i1, i2, i3), i_d < count[d], sits at base + sum_d i_d * stride[d]
+// (elements; strides may be negative).  Row-major order over the region = flat index of the dense side.
+struct dsc_region {
+    int count[4];
+    long long stride[4];
+    long long base;
+    long long ne;             // product of count
+};
+// gather: dense[i] = strided[region(i)];  scatter: strided[region(i)] = dense[i % dense_ne]
+void dsc_launch_region_copy(const void *src, void *dst, int elem_bytes, const dsc_region &r, bool scatter, long long dense_ne,
+                            hipStream_t stream);

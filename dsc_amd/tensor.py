@@ -85,6 +85,37 @@ class Tensor:
     def __rtruediv__(self, other):
         return true_div(other, self)
 
+    def __getitem__(self, item):
+        """python/dsc/tensor.py:193-229: ints -> dsc_tensor_get_idx (a fully indexed element is unwrapped to a
+        Python scalar), slices or mixed -> dsc_tensor_get_slice.  The copy happens on the device."""
+        ctx = _get_ctx()
+        if isinstance(item, int):
+            return _unwrap(Tensor(B.dsc_tensor_get_idx(ctx, self._c_ptr, item)))
+        if isinstance(item, tuple) and all(isinstance(i, int) for i in item):
+            return _unwrap(Tensor(B.dsc_tensor_get_idx(ctx, self._c_ptr, *item)))
+        if isinstance(item, slice):
+            return Tensor(B.dsc_tensor_get_slice(ctx, self._c_ptr, _c_slice(item)))
+        if isinstance(item, tuple) and all(isinstance(i, (int, slice)) for i in item):
+            return Tensor(B.dsc_tensor_get_slice(ctx, self._c_ptr, *[_c_slice(i) for i in item]))
+        raise RuntimeError(f'cannot index Tensor with object {item}')
+
+    def __setitem__(self, key, value):
+        """python/dsc/tensor.py:231-270"""
+        ctx = _get_ctx()
+        val = _wrap(value, self._dtype)
+        if val.dtype != self._dtype:
+            val = val.cast(self._dtype)
+        if isinstance(key, int):
+            B.dsc_tensor_set_idx(ctx, self._c_ptr, val._c_ptr, key)
+        elif isinstance(key, tuple) and all(isinstance(i, int) for i in key):
+            B.dsc_tensor_set_idx(ctx, self._c_ptr, val._c_ptr, *key)
+        elif isinstance(key, slice):
+            B.dsc_tensor_set_slice(ctx, self._c_ptr, val._c_ptr, _c_slice(key))
+        elif isinstance(key, tuple) and all(isinstance(i, (int, slice)) for i in key):
+            B.dsc_tensor_set_slice(ctx, self._c_ptr, val._c_ptr, *[_c_slice(i) for i in key])
+        else:
+            raise RuntimeError(f'cannot index Tensor with object {key}')
+
     def numpy(self) -> np.ndarray:
         """Device -> host copy (the reference returns a zero-copy view, tensor.py:305-323)."""
         out = np.empty(self._shape if self._n_dim > 0 else (1,), dtype=DTYPE_TO_NP[self._dtype])
@@ -101,6 +132,22 @@ class Tensor:
         out_ptr = B.dsc_cast(_get_ctx(), self._c_ptr, dtype.value)
         same = B.ctypes.cast(out_ptr, B.c_void_p).value == B.ctypes.cast(self._c_ptr, B.c_void_p).value
         return Tensor(out_ptr, view=same)
+
+
+def _unwrap(x: Tensor):
+    """python/dsc/tensor.py:91-103: a 1-element 1-D tensor becomes a Python scalar (one device -> host copy)."""
+    if x.n_dim != 1 or len(x) != 1:
+        return x
+    v = x.numpy()[0]
+    return complex(v) if np.iscomplexobj(v) else float(v)
+
+
+def _c_slice(x) -> 'B._DscSlice':
+    """python/dsc/tensor.py:106-118: None -> DSC_VALUE_NONE; an int inside a mixed key -> (i, i, i)."""
+    if isinstance(x, slice):
+        f = lambda i: B.DSC_VALUE_NONE if i is None else int(i)      # noqa: E731
+        return B._DscSlice(f(x.start), f(x.stop), f(x.step))
+    return B._DscSlice(int(x), int(x), int(x))
 
 
 def _create_tensor(dtype: Dtype, *dims: int) -> Tensor:

@@ -128,6 +128,26 @@ dsc_tensor *dsc_conj(dsc_ctx *ctx, dsc_tensor *x);
 dsc_tensor *dsc_real(dsc_ctx *ctx, dsc_tensor *x);
 dsc_tensor *dsc_imag(dsc_ctx *ctx, const dsc_tensor *x);
 
+/* dsc.h:110-117 — one slice per leading dimension; DSC_VALUE_NONE (dsc.h:78) in a field selects NumPy's
+ * default for it; start == stop == step != NONE means "this single index" and collapses the dimension
+ * (how the wrapper spells x[:, 1], tensor.py:106-118). */
+#define DSC_VALUE_NONE INT32_MAX
+typedef struct dsc_slice {
+    int start, stop, step;
+} dsc_slice;
+
+/* dsc.h:236-260, dsc.cpp:829-1169 — indexing and slicing ON THE DEVICE (SURVEY 8f "next" row 1): the
+ * `[:output_length]` crop after dsc_irfft and the placement of a block into a zero-padded buffer no longer
+ * round-trip through the host.  Variadic exactly as the reference: `indexes` ints, or `slices` dsc_slice
+ * structs BY VALUE.  get_* return a new contiguous tensor (a fully indexed element is a 1-element 1-D tensor);
+ * set_* write xb (same dtype; a 1-element tensor is broadcast, anything else is consumed cyclically in
+ * row-major order, dsc.cpp:1010-1041) into the selected region of xa.  Negative indexes / starts / stops count
+ * from the end, negative steps walk backwards; out-of-range arguments abort as the reference's asserts do. */
+dsc_tensor *dsc_tensor_get_idx(dsc_ctx *ctx, const dsc_tensor *x, int indexes, ...);
+dsc_tensor *dsc_tensor_get_slice(dsc_ctx *ctx, const dsc_tensor *x, int slices, ...);
+void dsc_tensor_set_idx(dsc_ctx *ctx, dsc_tensor *xa, const dsc_tensor *xb, int indexes, ...);
+void dsc_tensor_set_slice(dsc_ctx *ctx, dsc_tensor *xa, const dsc_tensor *xb, int slices, ...);
+
 /* dsc.h:358-380, dsc.cpp:1771-1953.  Sequential left-to-right accumulation order per
  * output element is NOT reproduced on the GPU (tree order); max/min are exact
  * including the reference's tie rules on the real part (dsc_ops.h:318-339). */

@@ -164,6 +164,63 @@ class Ref:
         self.free(tx)
         return out
 
+    # -- indexing / slicing (variadic C functions: dsc.h:244-260) --------------------
+    NONE = 2 ** 31 - 1
+
+    class Slice(Structure):
+        _fields_ = [('start', c_int), ('stop', c_int), ('step', c_int)]
+
+    @classmethod
+    def c_slice(cls, s):
+        if isinstance(s, slice):
+            f = lambda i: cls.NONE if i is None else int(i)      # noqa: E731
+            return cls.Slice(f(s.start), f(s.stop), f(s.step))
+        return cls.Slice(int(s), int(s), int(s))
+
+    def _setup_index(self):
+        L = self.L
+        if getattr(self, '_idx_ready', False):
+            return
+        L.dsc_tensor_get_idx.argtypes = [c_void_p, TP, c_int]
+        L.dsc_tensor_get_idx.restype = TP
+        L.dsc_tensor_get_slice.argtypes = [c_void_p, TP, c_int]
+        L.dsc_tensor_get_slice.restype = TP
+        L.dsc_tensor_set_idx.argtypes = [c_void_p, TP, TP, c_int]
+        L.dsc_tensor_set_idx.restype = None
+        L.dsc_tensor_set_slice.argtypes = [c_void_p, TP, TP, c_int]
+        L.dsc_tensor_set_slice.restype = None
+        self._idx_ready = True
+
+    def get_idx(self, x, *idx):
+        self._setup_index()
+        tx = self.put(x)
+        out = self.take(self.L.dsc_tensor_get_idx(self.ctx, tx, len(idx), *[c_int(i) for i in idx]))
+        self.free(tx)
+        return out
+
+    def get_slice(self, x, *key):
+        self._setup_index()
+        tx = self.put(x)
+        out = self.take(self.L.dsc_tensor_get_slice(self.ctx, tx, len(key), *[self.c_slice(k) for k in key]))
+        self.free(tx)
+        return out
+
+    def set_idx(self, xa, xb, *idx):
+        self._setup_index()
+        ta, tb = self.put(xa), self.put(xb)
+        self.L.dsc_tensor_set_idx(self.ctx, ta, tb, len(idx), *[c_int(i) for i in idx])
+        out = self.take(ta)
+        self.free(tb)
+        return out
+
+    def set_slice(self, xa, xb, *key):
+        self._setup_index()
+        ta, tb = self.put(xa), self.put(xb)
+        self.L.dsc_tensor_set_slice(self.ctx, ta, tb, len(key), *[self.c_slice(k) for k in key])
+        out = self.take(ta)
+        self.free(tb)
+        return out
+
     # -- raw handles, for timing loops in bench.py -----------------------------
     def rfft_raw(self, tx, tout):
         return self.L.dsc_rfft(self.ctx, tx, tout, -1, -1)

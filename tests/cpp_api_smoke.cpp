@@ -26,5 +26,11 @@ int main(int argc, char **argv) {
     double diff = 0, ref = 0;
     for (int i = 0; i < n; ++i) { diff += (h1[i] - h2[i]) * (h1[i] - h2[i]); ref += h1[i] * h1[i]; }
     std::printf("fused vs composed rel-L2 %.3e\n", std::sqrt(diff / ref));
-    return std::sqrt(diff / ref) < 1e-5 ? 0 : 1;
+    // the README's `[:output_length]` crop (README.md:133), on the device
+    auto crop = y.get(DSC_SLICE_ALL(), DSC_SLICE_TO(1000));
+    auto hc = crop.to_host();
+    bool crop_ok = crop.dim(-1) == 1000 && hc.size() == 1000;
+    for (int i = 0; i < 1000 && crop_ok; ++i) crop_ok = hc[i] == h1[i];
+    std::printf("crop %s\n", crop_ok ? "ok" : "MISMATCH");
+    return std::sqrt(diff / ref) < 1e-5 && crop_ok ? 0 : 1;
 }

@@ -161,6 +161,29 @@ def main():
             for op, name in enumerate(('abs', 'angle', 'conj', 'real', 'imag')):
                 add('unary', name, x, R.unary(x, op))
 
+    # ---- indexing / slicing: `sel` is the key, ints or [start, stop, step] with null = None
+    def enc(k):
+        return [None if v is None else int(v) for v in (k.start, k.stop, k.step)] if isinstance(k, slice) else int(k)
+
+    S = slice
+    for dt in ('f32', 'c32', 'f64', 'c64'):
+        x = rnd(rng, (3, 4, 5, 6), NP[dt])
+        x2 = rnd(rng, (7, 40), NP[dt])
+        for k in ((S(None),), (1,), (S(None), 2), (S(1, 3), S(None, None, -1), S(0, 5, 2), S(-4, -1)), (-1, S(None), -2, S(None, None, 3)),
+                  (S(2, 0, -1),), (S(None, None, -2), S(None), S(None), S(5, None, -2)), (S(None), S(None), S(None), 0)):
+            add('slice', 'get_slice', x, R.get_slice(x, *k), sel=[enc(i) for i in k])
+        for k in ((S(None), S(None, 17)), (S(None), S(3, None, 4)), (S(None, None, -1), S(None)), (-1, S(None, None, -1))):
+            add('slice', 'get_slice', x2, R.get_slice(x2, *k), sel=[enc(i) for i in k])
+        for idx in ((0,), (2, 3), (-1, -1, -1), (1, 2, 3, 4)):
+            add('slice', 'get_idx', x, R.get_idx(x, *idx), sel=list(idx))
+        one = rnd(rng, (1,), NP[dt])
+        for k, v in (((S(0, 2), 1), rnd(rng, (2, 1, 5, 6), NP[dt])), ((S(None), S(None), S(None), S(0, 3)), one),
+                     ((1, S(None, None, 2)), rnd(rng, (1, 2, 5, 6), NP[dt])), ((S(None), S(None), S(1, 4), S(None, None, -1)), rnd(rng, (3,), NP[dt])),
+                     ((S(None, None, -1),), rnd(rng, (3, 4, 5, 6), NP[dt]))):
+            add('slice', 'set_slice', (x, v), R.set_slice(x, v, *k), sel=[enc(i) for i in k])
+        for idx, v in (((1, 2, 3, 4), one), ((2,), one), ((0, 1), one), ((1,), rnd(rng, (3, 4, 5), NP[dt]))):
+            add('slice', 'set_idx', (x, v), R.set_idx(x, v, *idx), sel=list(idx))
+
     for group, g in arrays.items():
         np.savez_compressed(os.path.join(HERE, f'{group}.npz'), **g)
         print(group, len(g), 'arrays', os.path.getsize(os.path.join(HERE, f'{group}.npz')) // 1024, 'KiB')

@@ -92,3 +92,8 @@ class Golden:
             prev_y = y
             if op is None or rec['op'] == op:
                 yield rec, xs, y
+
+
+def decode_sel(sel):
+    """`sel` of a 'slice' golden record -> tuple of ints / slices (tests/golden/make_golden.py)."""
+    return tuple(slice(*k) if isinstance(k, list) else int(k) for k in sel)

@@ -236,3 +236,104 @@ def test_reduce_segmented_axis(dsc):
         for name, op in (('max', port.MAX), ('min', port.MIN)):
             got = getattr(dsc, name)(dsc.from_numpy(xq), axis=0, keepdims=False).numpy()
             assert np.array_equal(got, port.reduce(xq, op, 0, False)), (name, dt)
+
+
+def test_golden_indexing_and_slicing(dsc, golden):
+    """dsc_tensor_get_idx / get_slice / set_idx / set_slice on the device against the reference's
+    outputs (tests/golden/slice.npz): exact."""
+    from tests.helpers import decode_sel
+    n = 0
+    for rec, xs, y in golden.cases('slice'):
+        key = decode_sel(rec['sel'])
+        key1 = key[0] if len(key) == 1 else key
+        t = dsc.from_numpy(xs[0])
+        if rec['op'].startswith('get'):
+            got = t[key1]
+            got = got.numpy() if isinstance(got, dsc.Tensor) else np.array([got], dtype=y.dtype)
+        else:
+            t[key1] = dsc.from_numpy(xs[1])
+            got = t.numpy()
+        assert got.dtype == y.dtype and got.shape == y.shape, (rec['key'], got.shape, y.shape)
+        assert np.array_equal(got, y), rec['key']
+        n += 1
+    assert n == 100
+
+
+def test_slicing_random_keys_and_wide_rows(dsc):
+    """Random keys against the oracle, plus the shapes the hot path uses: the `[:output_length]` crop of
+    irfft rows (README.md:133), strided / reversed wide rows and block placement into a padded buffer."""
+    from oracle import indexing as ix
+    rng = np.random.default_rng(5)
+    n_ok = 0
+    for trial in range(200):
+        nd = int(rng.integers(1, 5))
+        shape = tuple(int(v) for v in rng.integers(1, 9, nd))
+        dt = (np.float32, np.float64, np.complex64, np.complex128)[trial % 4]
+        x = rng.standard_normal(shape).astype(dt)
+        key = []
+        for d in range(int(rng.integers(1, nd + 1))):
+            if rng.random() < 0.25:
+                key.append(int(rng.integers(-shape[d], shape[d])))
+            else:
+                f = lambda: None if rng.random() < 0.5 else int(rng.integers(-shape[d], shape[d] + 1))   # noqa: E731
+                key.append(slice(f(), f(), None if rng.random() < 0.5 else int(rng.integers(-3, 4))))
+        try:
+            want = ix.get_slice(x, *key)
+        except ix.Abort:
+            continue
+        k1 = key[0] if len(key) == 1 else tuple(key)
+        got = dsc.from_numpy(x)[k1]
+        got = got.numpy() if isinstance(got, dsc.Tensor) else np.array([got], dtype=dt)
+        if want.size == got.size and want.shape != got.shape:      # all-int key: the wrapper calls get_idx (1-element tensor)
+            want = want.reshape(got.shape)
+        assert got.shape == want.shape and np.array_equal(got, want), (shape, key)
+        v = rng.standard_normal(1 if trial % 2 else int(rng.integers(1, 9))).astype(dt)
+        try:
+            want_set = ix.set_slice(x, v, *key)
+        except ix.Abort:
+            continue
+        t = dsc.from_numpy(x)
+        if all(isinstance(k, int) for k in key):
+            continue                                               # int-only keys go to set_idx (its own shape rule)
+        t[k1] = dsc.from_numpy(v)
+        assert np.array_equal(t.numpy(), want_set), (shape, key, v.shape)
+        n_ok += 1
+    assert n_ok > 40
+    # wide rows (row kernel) and the filterFFT crop
+    y = rng.standard_normal((37, 4096)).astype(np.float32)
+    t = dsc.from_numpy(y)
+    assert np.array_equal(t[:, :3001].numpy(), y[:, :3001])
+    assert np.array_equal(t[::-2, 5:4000:3].numpy(), y[::-2, 5:4000:3])
+    assert np.array_equal(t[3:30, ::-1].numpy(), y[3:30, ::-1])
+    pad = dsc.from_numpy(np.zeros((37, 8192), np.float32))
+    pad[:, 100:4196] = t                                           # place a block into a zero-padded buffer
+    want = np.zeros((37, 8192), np.float32)
+    want[:, 100:4196] = y
+    assert np.array_equal(pad.numpy(), want)
+    z = (rng.standard_normal((5, 2049)) + 1j * rng.standard_normal((5, 2049))).astype(np.complex128)
+    assert np.array_equal(dsc.from_numpy(z)[1:4, 1:-1].numpy(), z[1:4, 1:-1])
+    # the whole README pipeline on the device: irfft(rfft(s) * rfft(b))[:, :ls + lb - 1]
+    s = rng.standard_normal((4, 3000)).astype(np.float32)
+    b = rng.standard_normal(97).astype(np.float32)
+    n = 4096
+    out = dsc.irfft(dsc.rfft(dsc.from_numpy(s), n=n) * dsc.rfft(dsc.from_numpy(b), n=n))[:, :3000 + 97 - 1]
+    ref_full = np.stack([np.convolve(r.astype(np.float64), b.astype(np.float64)) for r in s])
+    assert out.shape == (4, 3096) and np.abs(out.numpy() - ref_full).max() <= 1e-3
+
+
+def test_indexing_errors_abort_like_the_reference():
+    """Out-of-range / empty / mismatched selections exit (dsc.cpp:849, 926-931, 1050, 1146)."""
+    cases = {
+        'idx_range': 't[3]',
+        'slice_too_long': 't[0:9]',
+        'slice_empty': 't[2:1]',
+        'too_many': 't[0, 0, 0]',
+        'set_shape': 't[:] = dsc.from_numpy(np.zeros((2, 4), np.float32))',
+        'past_end': 't[2:5]',
+    }
+    for name, stmt in cases.items():
+        code = ('import numpy as np, dsc_amd as dsc\ndsc.init(1 << 26, 1 << 26)\n'
+                f't = dsc.from_numpy(np.zeros((3, 4), np.float32))\n{stmt}\ndsc.synchronize()\nprint("SURVIVED")')
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True)
+        assert r.returncode != 0 and 'SURVIVED' not in r.stdout, (name, r.stdout, r.stderr)
+        assert 'DSC_ASSERT' in r.stderr or 'too many' in r.stderr, (name, r.stderr)

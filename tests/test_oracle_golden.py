@@ -119,3 +119,31 @@ def test_unary_spectrum_consumers(golden):
         assert np.allclose(got, y, rtol=2e-6 if y.dtype == np.float32 or y.dtype == np.complex64 else 4e-15, atol=1e-30), rec['key']
         n += 1
     assert n == 40
+
+
+def test_indexing_and_slicing(golden):
+    """oracle/indexing.py (restatement of dsc.cpp:829-1169) against the reference's outputs: exact."""
+    from oracle import indexing as ix
+    from tests.helpers import decode_sel
+    n = 0
+    for rec, xs, y in golden.cases('slice'):
+        key = decode_sel(rec['sel'])
+        got = getattr(ix, rec['op'])(*xs, *key)
+        assert got.dtype == y.dtype and got.shape == y.shape, rec['key']
+        assert np.array_equal(got, y), rec['key']
+        n += 1
+    assert n == 100
+
+
+def test_indexing_aborts_where_the_reference_asserts():
+    from oracle import indexing as ix
+    x = np.zeros((3, 4), np.float32)
+    for bad in ((slice(0, 9),), (slice(2, 1),), (slice(None, None, 0),), (slice(None), slice(None), 0)):
+        with pytest.raises(ix.Abort):
+            ix.get_slice(x, *bad)
+    with pytest.raises(ix.Abort):
+        ix.get_idx(x, 3)
+    with pytest.raises(ix.Abort):
+        ix.set_slice(x, np.zeros((2, 4), np.float32), slice(None))          # dsc.cpp:1146
+    with pytest.raises(ix.Abort):
+        ix.set_idx(x, np.zeros(4, np.float64), 0)                            # dtype mismatch, dsc.cpp:1050

@@ -91,3 +91,39 @@ def test_plan_table_layout():
     want = np.exp(-2j * np.pi * k / 65536)
     got = tw[base::2] + 1j * tw[base + 1::2]
     assert np.max(np.abs(got - want)) < 3e-7
+
+
+def test_indexing_random_keys():
+    """oracle/indexing.py against the reference on random keys (every call the oracle accepts is
+    replayed on the reference; refused ones would exit the process there)."""
+    from oracle import indexing as ix
+    R = ref.Ref.get()
+    rng = np.random.default_rng(77)
+    n_ok = 0
+    for trial in range(300):
+        nd = int(rng.integers(1, 5))
+        shape = tuple(int(v) for v in rng.integers(1, 7, nd))
+        dt = DTS[trial % 4]
+        x = rnd(rng, shape, dt)
+        key = []
+        for d in range(int(rng.integers(1, nd + 1))):
+            if rng.random() < 0.25:
+                key.append(int(rng.integers(-shape[d], shape[d])))
+            else:
+                f = lambda: None if rng.random() < 0.4 else int(rng.integers(-shape[d] - 1, shape[d] + 2))   # noqa: E731
+                step = None if rng.random() < 0.5 else int(rng.integers(-3, 4))
+                key.append(slice(f(), f(), step))
+        try:
+            want_get = ix.get_slice(x, *key)
+        except ix.Abort:
+            continue
+        got = R.get_slice(x, *key)
+        assert got.shape == want_get.shape and np.array_equal(got, want_get), (shape, key)
+        v = rnd(rng, (1,), dt) if trial % 2 else rnd(rng, (int(rng.integers(1, 9)),), dt)
+        try:
+            want_set = ix.set_slice(x, v, *key)
+        except ix.Abort:
+            continue
+        assert np.array_equal(R.set_slice(x, v, *key), want_set), (shape, key, v.shape)
+        n_ok += 1
+    assert n_ok > 60
