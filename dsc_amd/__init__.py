@@ -7,8 +7,8 @@ C ABI in include/dsc_mi355x.h through ctypes; importing this package without the
 library raises."""
 from .context import clear, init, last_fft_path, shutdown, synchronize, used_mem
 from .dtype import Dtype
-from .tensor import (Tensor, absolute, add, angle, conj, imag, real, empty, fft, filter_fft, from_numpy, ifft, irfft, max, mean, min, mul, plan_fft, rfft, sub, sum,
+from .tensor import (Tensor, absolute, add, angle, conj, imag, real, empty, fft, fftfreq, filter_fft, from_numpy, ifft, irfft, max, mean, min, mul, plan_fft, rfft, rfftfreq, sub, sum, transpose,
                      true_div)
 
 __all__ = ['init', 'clear', 'shutdown', 'synchronize', 'used_mem', 'last_fft_path', 'Dtype', 'Tensor', 'empty',
-           'from_numpy', 'mul', 'add', 'sub', 'true_div', 'absolute', 'angle', 'conj', 'real', 'imag', 'sum', 'mean', 'max', 'min', 'plan_fft', 'fft', 'ifft', 'rfft', 'irfft', 'filter_fft']
+           'from_numpy', 'mul', 'add', 'sub', 'true_div', 'absolute', 'angle', 'conj', 'real', 'imag', 'sum', 'mean', 'max', 'min', 'plan_fft', 'fft', 'ifft', 'rfft', 'irfft', 'filter_fft', 'transpose', 'fftfreq', 'rfftfreq']

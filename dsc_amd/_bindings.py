@@ -122,6 +122,15 @@ def dsc_tensor_set_slice(ctx, xa, xb, *slices):
     _dsc_tensor_set_slice(ctx, xa, xb, len(slices), *slices)
 
 
+_dsc_transpose = _sig('dsc_transpose', _DscTensor_p, _DscCtx, _DscTensor_p, c_int)
+
+
+def dsc_transpose(ctx, x, *axes):
+    return _dsc_transpose(ctx, x, len(axes), *[c_int(a) for a in axes])
+
+
+dsc_fftfreq = _sig('dsc_fftfreq', _DscTensor_p, _DscCtx, c_int, c_double, c_uint8)
+dsc_rfftfreq = _sig('dsc_rfftfreq', _DscTensor_p, _DscCtx, c_int, c_double, c_uint8)
 dsc_set_device = _sig('dsc_set_device', c_int, c_int)
 dsc_copy_from_host = _sig('dsc_copy_from_host', None, _DscCtx, _DscTensor_p, c_void_p, c_size_t)
 dsc_copy_to_host = _sig('dsc_copy_to_host', None, _DscCtx, _DscTensor_p, c_void_p, c_size_t)

@@ -269,3 +269,47 @@ void dsc_launch_region_copy(const void *src, void *dst, int elem_bytes, const ds
         default: region_typed<b16>(src, dst, r, scatter, dense_ne, stream); break;
     }
 }
+
+// ---- dsc_transpose of the last two axes (dsc.cpp:764-827 walks a stride iterator per element) ----
+namespace {
+
+template<typename E>
+__global__ void transpose_last2_kernel(const E *in, E *out, int rows, int cols, unsigned tiles_c, unsigned tiles_r) {
+    __shared__ E tile[32][33];
+    const unsigned long long blk = blockIdx.x;
+    const unsigned long long per = (unsigned long long) tiles_c * tiles_r;
+    const unsigned long long b = blk / per;
+    const unsigned rem = (unsigned) (blk - b * per);
+    const unsigned tr = rem / tiles_c, tc = rem - tr * tiles_c;
+    const E *src = in + b * (unsigned long long) rows * cols;
+    E *dst = out + b * (unsigned long long) rows * cols;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;              // 32 x 8 threads
+    for (int k = ty; k < 32; k += 8) {
+        const int r = tr * 32 + k, c = tc * 32 + tx;
+        if (r < rows && c < cols) tile[k][tx] = src[(long long) r * cols + c];
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = tc * 32 + k, r = tr * 32 + tx;
+        if (r < rows && c < cols) dst[(long long) c * rows + r] = tile[tx][k];
+    }
+}
+
+template<typename E>
+void transpose_typed(const void *in, void *out, long long batch, int rows, int cols, hipStream_t s) {
+    const unsigned tiles_c = (cols + 31) / 32, tiles_r = (rows + 31) / 32;
+    const unsigned long long blocks = (unsigned long long) batch * tiles_c * tiles_r;
+    hipLaunchKernelGGL((transpose_last2_kernel<E>), dim3((unsigned) blocks), dim3(256), 0, s, (const E *) in, (E *) out, rows, cols, tiles_c,
+                       tiles_r);
+}
+
+}  // namespace
+
+void dsc_launch_transpose_last2(const void *in, void *out, int elem_bytes, long long batch, int rows, int cols, hipStream_t stream) {
+    if (batch <= 0 || rows <= 0 || cols <= 0) return;
+    switch (elem_bytes) {
+        case 4:  transpose_typed<unsigned int>(in, out, batch, rows, cols, stream); break;
+        case 8:  transpose_typed<unsigned long long>(in, out, batch, rows, cols, stream); break;
+        default: transpose_typed<b16>(in, out, batch, rows, cols, stream); break;
+    }
+}

@@ -219,3 +219,94 @@ extern "C" void dsc_tensor_set_slice(dsc_ctx *ctx, dsc_tensor *xa, const dsc_ten
     }
     tensor_set(ctx, xa, xb, slices, el_slices);
 }
+
+// ------------------------------------------------------------------------------------------------
+// dsc.cpp:764-827
+extern "C" dsc_tensor *dsc_transpose(dsc_ctx *ctx, const dsc_tensor *x, int axes, ...) {
+    DSC_ASSERT(x != nullptr);
+    if (x->n_dim == 1) return dsc_view(ctx, x);
+
+    int swap_axes[DSC_MAX_DIMS];
+    if (axes == 0) {
+        for (int i = 0; i < x->n_dim; ++i) swap_axes[i] = x->n_dim - (i + 1);
+    } else {
+        DSC_ASSERT(axes == x->n_dim);
+        va_list args;
+        va_start(args, axes);
+        for (int i = 0; i < axes; ++i) {
+            const int el = va_arg(args, int);
+            DSC_ASSERT((unsigned) el < DSC_MAX_DIMS);
+            DSC_ASSERT(el < x->n_dim);                  // the reference indexes past its arrays here
+            swap_axes[i] = el;
+        }
+        va_end(args);
+    }
+
+    int swapped_shape[DSC_MAX_DIMS], swapped_stride[DSC_MAX_DIMS];
+    for (int i = 0; i < DSC_MAX_DIMS - x->n_dim; ++i) {
+        swapped_shape[i] = x->shape[i];
+        swapped_stride[i] = x->stride[i];
+    }
+    for (int i = 0; i < x->n_dim; ++i) {
+        const int idx = tensor_dim(x, swap_axes[i]);
+        swapped_shape[tensor_dim(x, i)] = x->shape[idx];
+        swapped_stride[tensor_dim(x, i)] = x->stride[idx];
+    }
+    dsc_tensor *out = dsc_new_tensor(ctx, x->n_dim, &swapped_shape[tensor_dim(x, 0)], x->dtype, nullptr);
+    const int esz = (int) dsc_dtype_size(x->dtype);
+
+    // leading axes in place and the last two swapped: tiled transpose, coalesced on both sides
+    bool last2 = swap_axes[x->n_dim - 1] == x->n_dim - 2 && swap_axes[x->n_dim - 2] == x->n_dim - 1;
+    for (int i = 0; i < x->n_dim - 2; ++i) last2 = last2 && swap_axes[i] == i;
+    if (last2) {
+        const int rows = x->shape[DSC_MAX_DIMS - 2], cols = x->shape[DSC_MAX_DIMS - 1];
+        dsc_launch_transpose_last2(x->data, out->data, esz, (long long) x->ne / ((long long) rows * cols), rows, cols, ctx->stream);
+        return out;
+    }
+    // copy_with_stride (dsc.cpp:748-762): out is walked densely, x through the permuted strides
+    dsc_region r;
+    r.base = 0;
+    r.ne = out->ne;
+    for (int d = 0; d < DSC_MAX_DIMS; ++d) { r.count[d] = swapped_shape[d]; r.stride[d] = swapped_stride[d]; }
+    dsc_launch_region_copy(x->data, out->data, esz, r, false, out->ne, ctx->stream);
+    return out;
+}
+
+// dsc.cpp:2262-2340: the values are computed on the host in T with the reference's own expressions and copied once
+template<typename T>
+static void fill_fftfreq(T *v, int n, T d) {
+    const T factor = 1 / (n * d);
+    const int odd = n & 1;
+    const int n2 = odd ? ((n - 1) >> 1) : (n >> 1);
+    for (int i = 0; i < (n2 + odd); ++i) v[i] = i * factor;
+    for (int i = 0; i < n2; ++i) v[(n2 + odd) + i] = (-n2 + i) * factor;
+}
+template<typename T>
+static void fill_rfftfreq(T *v, int count, int n, T d) {
+    const T factor = 1 / (n * d);
+    for (int i = 0; i < count; ++i) v[i] = i * factor;
+}
+
+static dsc_tensor *freq_entry(dsc_ctx *ctx, int n, double d, dsc_dtype dtype, bool real_bins) {
+    DSC_ASSERT(n > 0);
+    if (dtype != DSC_F32 && dtype != DSC_F64) DSC_LOG_FATAL("dtype must be real");
+    const int count = real_bins ? ((n & 1) ? (((n - 1) >> 1) + 1) : ((n >> 1) + 1)) : n;
+    dsc_tensor *out = dsc_tensor_1d(ctx, dtype, count);
+    const size_t bytes = (size_t) count * dsc_dtype_size(dtype);
+    void *host = malloc(bytes);
+    DSC_ASSERT(host != nullptr);
+    if (dtype == DSC_F32) {
+        if (real_bins) fill_rfftfreq((float *) host, count, n, (float) d);
+        else           fill_fftfreq((float *) host, n, (float) d);
+    } else {
+        if (real_bins) fill_rfftfreq((double *) host, count, n, d);
+        else           fill_fftfreq((double *) host, n, d);
+    }
+    HIP_CHECK(hipMemcpyAsync(out->data, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    free(host);
+    return out;
+}
+
+extern "C" dsc_tensor *dsc_fftfreq(dsc_ctx *ctx, int n, double d, dsc_dtype dtype) { return freq_entry(ctx, n, d, dtype, false); }
+extern "C" dsc_tensor *dsc_rfftfreq(dsc_ctx *ctx, int n, double d, dsc_dtype dtype) { return freq_entry(ctx, n, d, dtype, true); }

@@ -129,3 +129,6 @@ struct dsc_region {
 // gather: dense[i] = strided[region(i)];  scatter: strided[region(i)] = dense[i % dense_ne]
 void dsc_launch_region_copy(const void *src, void *dst, int elem_bytes, const dsc_region &r, bool scatter, long long dense_ne,
                             hipStream_t stream);
+
+// out[b][c][r] = in[b][r][c] for `batch` matrices of rows x cols elements (32 x 32 tiles through LDS: both sides coalesced)
+void dsc_launch_transpose_last2(const void *in, void *out, int elem_bytes, long long batch, int rows, int cols, hipStream_t stream);

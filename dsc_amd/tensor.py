@@ -304,3 +304,17 @@ def irfft(x: Tensor, out=None, n: int = -1, axis: int = -1) -> Tensor:
 def filter_fft(s: Tensor, H: Tensor, out=None) -> Tensor:
     """irfft(rfft(s, n) * H) with n = 2 * (len(H) - 1), fused where a kernel exists."""
     return Tensor(B.dsc_filter_fft(_get_ctx(), s._c_ptr, H._c_ptr, _c_ptr_or_none(out)), out is not None)
+
+
+def transpose(x: Tensor, axes=None) -> Tensor:                            # python/dsc/tensor.py:407-416
+    if axes is None or (isinstance(axes, (tuple, list)) and all(isinstance(a, int) for a in axes)):
+        return Tensor(B.dsc_transpose(_get_ctx(), x._c_ptr, *(tuple(axes) if axes is not None else ())))
+    raise RuntimeError(f'cannot transpose axes {axes}')
+
+
+def fftfreq(n: int, d: float = 1.0, dtype: Dtype = Dtype.F32) -> Tensor:   # python/dsc/tensor.py:729-730
+    return Tensor(B.dsc_fftfreq(_get_ctx(), n, d, dtype.value))
+
+
+def rfftfreq(n: int, d: float = 1.0, dtype: Dtype = Dtype.F32) -> Tensor:  # python/dsc/tensor.py:733-734
+    return Tensor(B.dsc_rfftfreq(_get_ctx(), n, d, dtype.value))

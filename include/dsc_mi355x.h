@@ -148,6 +148,15 @@ dsc_tensor *dsc_tensor_get_slice(dsc_ctx *ctx, const dsc_tensor *x, int slices, 
 void dsc_tensor_set_idx(dsc_ctx *ctx, dsc_tensor *xa, const dsc_tensor *xb, int indexes, ...);
 void dsc_tensor_set_slice(dsc_ctx *ctx, dsc_tensor *xa, const dsc_tensor *xb, int slices, ...);
 
+/* dsc.h:233-235, dsc.cpp:764-827 — permutation of the axes into a new contiguous tensor;
+ * `axes` = 0 reverses them, otherwise `axes` == n_dim ints follow.  A 1-D tensor returns a view, as the reference. */
+dsc_tensor *dsc_transpose(dsc_ctx *ctx, const dsc_tensor *x, int axes, ...);
+
+/* dsc.h:416-424, dsc.cpp:2262-2340 — bin centre frequencies; dtype must be real.  Computed in
+ * the output precision exactly as the reference does, then placed in HBM. */
+dsc_tensor *dsc_fftfreq(dsc_ctx *ctx, int n, double d, dsc_dtype dtype);
+dsc_tensor *dsc_rfftfreq(dsc_ctx *ctx, int n, double d, dsc_dtype dtype);
+
 /* dsc.h:358-380, dsc.cpp:1771-1953.  Sequential left-to-right accumulation order per
  * output element is NOT reproduced on the GPU (tree order); max/min are exact
  * including the reference's tie rules on the real part (dsc_ops.h:318-339). */

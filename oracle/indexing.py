@@ -166,3 +166,46 @@ def set_idx(xa, xb, *idx):
         for i in range(sub_ndim):
             _check(sub_shape[i] == xb.shape[i], 'xb shape')
     return _tensor_set(xa, xb, parsed)
+
+
+def transpose(x, axes=None):
+    """dsc.cpp:764-827 with copy_with_stride (:748-762): out is dense, x is read through the permuted strides."""
+    x = np.ascontiguousarray(x)
+    if x.ndim == 1:
+        return x.copy()
+    if axes is None or len(axes) == 0:
+        axes = [x.ndim - (i + 1) for i in range(x.ndim)]
+    _check(len(axes) == x.ndim, 'axes == n_dim')
+    for a in axes:
+        _check(0 <= a < x.ndim, 'axis in range')
+    strides = [int(np.prod(x.shape[i + 1:])) for i in range(x.ndim)]
+    sw_shape = [x.shape[a] for a in axes]
+    sw_stride = [strides[a] for a in axes]
+    offs = np.zeros(1, dtype=np.int64)
+    for n, st in zip(sw_shape, sw_stride):
+        offs = (offs[:, None] + np.arange(n, dtype=np.int64)[None, :] * st).reshape(-1)
+    return x.reshape(-1)[offs].reshape(sw_shape)
+
+
+def fftfreq(n, d=1.0, dtype=np.float32):
+    """dsc.cpp:2262-2302, evaluated in the output precision T: factor = 1 / (n * d); i * factor"""
+    _check(n > 0, 'n > 0')
+    T = np.dtype(dtype).type
+    factor = T(1) / (T(n) * T(d))
+    odd = n & 1
+    n2 = (n - 1) >> 1 if odd else n >> 1
+    out = np.empty(n, dtype=dtype)
+    for i in range(n2 + odd):
+        out[i] = T(i) * factor
+    for i in range(n2):
+        out[n2 + odd + i] = T(-n2 + i) * factor
+    return out
+
+
+def rfftfreq(n, d=1.0, dtype=np.float32):
+    """dsc.cpp:2304-2340"""
+    _check(n > 0, 'n > 0')
+    T = np.dtype(dtype).type
+    factor = T(1) / (T(n) * T(d))
+    count = ((n - 1) >> 1) + 1 if n & 1 else (n >> 1) + 1
+    return np.array([T(i) * factor for i in range(count)], dtype=dtype)

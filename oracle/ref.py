@@ -221,6 +221,25 @@ class Ref:
         self.free(tb)
         return out
 
+    def transpose(self, x, axes=None):
+        from ctypes import c_double  # noqa: F401
+        L = self.L
+        L.dsc_transpose.argtypes = [c_void_p, TP, c_int]
+        L.dsc_transpose.restype = TP
+        tx = self.put(x)
+        axes = tuple(axes) if axes is not None else ()
+        to = L.dsc_transpose(self.ctx, tx, len(axes), *[c_int(a) for a in axes])
+        out = self.take(to)
+        self.free(tx)
+        return out
+
+    def fftfreq(self, n, d, dtype, real_bins=False):
+        from ctypes import c_double
+        f = self.L.dsc_rfftfreq if real_bins else self.L.dsc_fftfreq
+        f.argtypes = [c_void_p, c_int, c_double, c_uint8]
+        f.restype = TP
+        return self.take(f(self.ctx, n, d, NP_TO_DT[np.dtype(dtype)]))
+
     # -- raw handles, for timing loops in bench.py -----------------------------
     def rfft_raw(self, tx, tout):
         return self.L.dsc_rfft(self.ctx, tx, tout, -1, -1)

@@ -184,6 +184,17 @@ def main():
         for idx, v in (((1, 2, 3, 4), one), ((2,), one), ((0, 1), one), ((1,), rnd(rng, (3, 4, 5), NP[dt]))):
             add('slice', 'set_idx', (x, v), R.set_idx(x, v, *idx), sel=list(idx))
 
+    # ---- transpose / fftfreq / rfftfreq
+    for dt in ('f32', 'c32', 'f64', 'c64'):
+        for shape, axes in (((5, 7), None), ((40, 70), (1, 0)), ((2, 3, 4), None), ((2, 3, 4), (0, 2, 1)), ((2, 3, 4), (1, 2, 0)),
+                            ((2, 3, 4, 5), None), ((2, 3, 4, 5), (0, 1, 3, 2)), ((2, 3, 4, 5), (3, 0, 2, 1)), ((9,), None)):
+            x = rnd(rng, shape, NP[dt])
+            add('layout', 'transpose', x, R.transpose(x, axes), axes=list(axes) if axes else None)
+    for dt in ('f32', 'f64'):
+        for n, d in ((8, 1.0), (9, 0.5), (1024, 1.0 / 44100), (1000, 0.001), (1, 2.0)):
+            add('layout', 'fftfreq', np.zeros(1, NP[dt]), R.fftfreq(n, d, NP[dt]), n=n, d=d)
+            add('layout', 'rfftfreq', np.zeros(1, NP[dt]), R.fftfreq(n, d, NP[dt], True), n=n, d=d)
+
     for group, g in arrays.items():
         np.savez_compressed(os.path.join(HERE, f'{group}.npz'), **g)
         print(group, len(g), 'arrays', os.path.getsize(os.path.join(HERE, f'{group}.npz')) // 1024, 'KiB')

@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import pytest
 
-from tests.helpers import assert_close
+from tests.helpers import assert_close, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -337,3 +337,30 @@ def test_indexing_errors_abort_like_the_reference():
         r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True)
         assert r.returncode != 0 and 'SURVIVED' not in r.stdout, (name, r.stdout, r.stderr)
         assert 'DSC_ASSERT' in r.stderr or 'too many' in r.stderr, (name, r.stderr)
+
+
+def test_golden_transpose_and_fftfreq(dsc, golden):
+    """dsc_transpose (tiled last-two-axes kernel and the general permutation) and dsc_fftfreq / dsc_rfftfreq against
+    the reference's outputs: exact."""
+    n = 0
+    for rec, xs, y in golden.cases('layout'):
+        if rec['op'] == 'transpose':
+            got = dsc.transpose(dsc.from_numpy(xs[0]), rec['axes']).numpy()
+        else:
+            dt = dsc.Dtype.F32 if y.dtype == np.float32 else dsc.Dtype.F64
+            got = getattr(dsc, rec['op'])(rec['n'], rec['d'], dt).numpy()
+        assert got.dtype == y.dtype and got.shape == y.shape, rec['key']
+        assert np.array_equal(got, y), rec['key']
+        n += 1
+    assert n == 56
+    rng = np.random.default_rng(8)
+    for shape in ((1000, 37), (33, 4097), (3, 130, 65)):                     # ragged tiles
+        for dt in (np.float32, np.complex64, np.complex128):
+            x = rng.standard_normal(shape).astype(dt)
+            ax = tuple(range(len(shape) - 2)) + (len(shape) - 1, len(shape) - 2)
+            assert np.array_equal(dsc.transpose(dsc.from_numpy(x), ax).numpy(), x.transpose(ax))
+    # a transform along axis 0 equals transpose -> last-axis transform -> transpose
+    x = rng.standard_normal((256, 24)).astype(np.float32)
+    a = dsc.rfft(dsc.from_numpy(x), axis=0).numpy()
+    b = dsc.transpose(dsc.rfft(dsc.transpose(dsc.from_numpy(x)))).numpy()
+    assert rel_l2(a, b) <= 1e-6

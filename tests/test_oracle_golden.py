@@ -147,3 +147,17 @@ def test_indexing_aborts_where_the_reference_asserts():
         ix.set_slice(x, np.zeros((2, 4), np.float32), slice(None))          # dsc.cpp:1146
     with pytest.raises(ix.Abort):
         ix.set_idx(x, np.zeros(4, np.float64), 0)                            # dtype mismatch, dsc.cpp:1050
+
+
+def test_transpose_and_fftfreq(golden):
+    from oracle import indexing as ix
+    n = 0
+    for rec, xs, y in golden.cases('layout'):
+        if rec['op'] == 'transpose':
+            got = ix.transpose(xs[0], rec['axes'])
+        else:
+            got = getattr(ix, rec['op'])(rec['n'], rec['d'], y.dtype)
+        assert got.dtype == y.dtype and got.shape == y.shape, rec['key']
+        assert np.array_equal(got, y), rec['key']
+        n += 1
+    assert n == 56
