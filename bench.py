@@ -23,6 +23,7 @@ import contextlib
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -103,6 +104,7 @@ def main():
     ap.add_argument('--batch', type=int, default=BATCH, help='rows per GPU (default: BASELINE config 2)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-allgather', action='store_true')
+    ap.add_argument('--allgather-timeout', type=float, default=180.0, help='seconds the separate RCCL all-gather phase may take before it is abandoned')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (gloo for the CPU dry run)')
     ap.add_argument('--dry-run', action='store_true', help='exercise the multi-process plumbing without a GPU (tests)')
     ap.add_argument('--share-device', action='store_true', help='testing aid: every rank uses device 0 (rehearse N > 1 on a one-GPU box; use with --backend gloo)')
@@ -191,41 +193,6 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- all-gather of the output shards over xGMI: its own phase, never part of `value`
-    if dist is not None and not args.dry_run and not args.no_allgather and args.backend == 'nccl':
-        try:
-            chunk_rows = 1024
-            bins = N_FFT // 2 + 1
-
-            class _DevView:          # zero-copy torch view of arena memory
-                def __init__(self, ptr, n_f32):
-                    self.__cuda_array_interface__ = {'shape': (n_f32,), 'typestr': '<f4', 'data': (ptr, False), 'version': 2}
-
-            base = out._c_ptr.contents.data
-            recv = torch.empty((world, chunk_rows * bins * 2), dtype=torch.float32, device='cuda')
-            views = [torch.as_tensor(_DevView(base + c * bins * 8, chunk_rows * bins * 2), device='cuda')
-                     for c in range(0, rows, chunk_rows)]
-            dist.all_gather_into_tensor(recv, views[0])       # warm-up: communicator + buffers
-            barrier_sync()
-            g0 = time.perf_counter()
-            for v in views:
-                dist.all_gather_into_tensor(recv, v)
-            barrier_sync()
-            g = time.perf_counter() - g0
-            tg = torch.tensor([g], dtype=torch.float64, device='cuda')
-            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-            g = float(tg.item())
-            shard_bytes = rows * bins * 8
-            extra['allgather'] = {
-                'ms': round(g * 1e3, 3),
-                'recv_GBps_per_gpu': round((world - 1) * shard_bytes / g / 1e9, 1),
-                'shard_bytes': shard_bytes,
-                'note': 'RCCL all_gather_into_tensor of every c32 shard, 1024-row chunks into a reused buffer; '
-                        'separate phase, not included in value',
-            }
-        except Exception as e:       # the metric must survive a collective problem
-            extra['allgather'] = {'error': repr(e)[:200]}
-
     if rank == 0:
         total_samples = world * rows * N_FFT * args.steps
         ms_per_step = elapsed / args.steps * 1e3
@@ -271,12 +238,70 @@ def main():
             if world == 1 and not args.no_cpu_baseline:
                 line['cpu_baseline'] = cpu_baseline()
                 line['cpu_baseline']['gpu_over_cpu'] = round(line['value'] / line['cpu_baseline']['value'], 1)
+    else:
+        line = None
+
+    # A collective that never returns must not cost the measurement above: past the deadline every rank leaves
+    # (rank 0 prints the line first, with the reason in `allgather`).
+    def deadline(seconds, what):
+        def bail():
+            if rank == 0 and not printed[0]:
+                line['allgather'] = {'error': f'{what} did not finish within {seconds:.0f} s; skipped'}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+        t = threading.Timer(seconds, bail)
+        t.daemon = True
+        t.start()
+        return t
+
+    printed = [False]
+    # ---- all-gather of the output shards over xGMI: its own phase, never part of `value`
+    if dist is not None and not args.dry_run and not args.no_allgather and args.backend == 'nccl':
+        guard = deadline(args.allgather_timeout, 'RCCL all-gather phase')
+        try:
+            chunk_rows = 1024
+            bins = N_FFT // 2 + 1
+
+            class _DevView:          # zero-copy torch view of arena memory
+                def __init__(self, ptr, n_f32):
+                    self.__cuda_array_interface__ = {'shape': (n_f32,), 'typestr': '<f4', 'data': (ptr, False), 'version': 2}
+
+            base = out._c_ptr.contents.data
+            recv = torch.empty((world, chunk_rows * bins * 2), dtype=torch.float32, device='cuda')
+            views = [torch.as_tensor(_DevView(base + c * bins * 8, chunk_rows * bins * 2), device='cuda')
+                     for c in range(0, rows, chunk_rows)]
+            dist.all_gather_into_tensor(recv, views[0])       # warm-up: communicator + buffers
+            barrier_sync()
+            g0 = time.perf_counter()
+            for v in views:
+                dist.all_gather_into_tensor(recv, v)
+            barrier_sync()
+            g = time.perf_counter() - g0
+            tg = torch.tensor([g], dtype=torch.float64, device='cuda')
+            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+            g = float(tg.item())
+            shard_bytes = rows * bins * 8
+            extra['allgather'] = {
+                'ms': round(g * 1e3, 3),
+                'recv_GBps_per_gpu': round((world - 1) * shard_bytes / g / 1e9, 1),
+                'shard_bytes': shard_bytes,
+                'note': 'RCCL all_gather_into_tensor of every c32 shard, 1024-row chunks into a reused buffer; '
+                        'separate phase, not included in value',
+            }
+        except Exception as e:       # the metric must survive a collective problem
+            extra['allgather'] = {'error': repr(e)[:200]}
+        guard.cancel()
+
+    if rank == 0:
         line.update(extra)
         print(json.dumps(line), flush=True)
+        printed[0] = True
 
     if dist is not None:
+        guard = deadline(120.0, 'process-group shutdown')
         dist.barrier()
         dist.destroy_process_group()
+        guard.cancel()
 
 
 if __name__ == '__main__':
