@@ -1,0 +1,128 @@
+// fft_regs_common.h — device building blocks of the register-resident FFT kernels (fft_regs_mid.hip,
+// fft_r2c_256k_f64_2pass.hip): complex arithmetic, in-register radix-2 DIF DFTs of 2..32 points with
+// compile-time twiddles (results in bit-reversed register order), the LDS-only barrier and buffer
+// load / store wrappers.  Header-only, everything in an anonymous namespace.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <utility>
+
+namespace {
+
+
+template<typename R> struct alignas(2 * sizeof(R)) cpx { R x, y; };
+
+template<typename R> __device__ __forceinline__ cpx<R> operator+(cpx<R> a, cpx<R> b) { return cpx<R>{a.x + b.x, a.y + b.y}; }
+template<typename R> __device__ __forceinline__ cpx<R> operator-(cpx<R> a, cpx<R> b) { return cpx<R>{a.x - b.x, a.y - b.y}; }
+template<typename R> __device__ __forceinline__ cpx<R> cmul(cpx<R> a, cpx<R> w) { return cpx<R>{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
+template<typename R> __device__ __forceinline__ cpx<R> cmulc(cpx<R> a, cpx<R> w) { return cpx<R>{a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y}; }
+
+__host__ __device__ constexpr int brev(int x, int bits) {
+    int r = 0;
+    for (int i = 0; i < bits; ++i) r |= ((x >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+__host__ __device__ constexpr int ilog2(int x) { return x <= 1 ? 0 : 1 + ilog2(x >> 1); }
+
+// cos(2 pi q / 64), q = 0..16
+__device__ constexpr double kCos64[17] = {
+    1.0, 0.99518472667219688624, 0.98078528040323044913, 0.95694033573220886494,
+    0.92387953251128675613, 0.88192126434835502971, 0.83146961230254523708, 0.77301045336273696081,
+    0.70710678118654752440, 0.63439328416364549822, 0.55557023301960222474, 0.47139673682599764856,
+    0.38268343236508977173, 0.29028467725446236764, 0.19509032201612826785, 0.09801714032956060199,
+    0.0};
+__device__ constexpr double root64_re(int q) {
+    q &= 63;
+    return q <= 16 ? kCos64[q] : q <= 32 ? -kCos64[32 - q] : q <= 48 ? -kCos64[q - 32] : kCos64[64 - q];
+}
+__device__ constexpr double root64_im(int q) {      // -sin(2 pi q / 64)
+    q &= 63;
+    return q <= 16 ? -kCos64[16 - q] : q <= 32 ? -kCos64[q - 16] : q <= 48 ? kCos64[48 - q] : kCos64[q - 48];
+}
+
+// d * W_M^K (forward) or d * conj(W_M^K) (INV), K < M/2, M <= 32
+template<typename R, bool INV, int M, int K>
+__device__ __forceinline__ cpx<R> mul_root(cpx<R> d) {
+    constexpr R c8 = (R) 0.70710678118654752440;
+    if constexpr (K == 0) {
+        return d;
+    } else if constexpr (4 * K == M) {
+        return INV ? cpx<R>{-d.y, d.x} : cpx<R>{d.y, -d.x};
+    } else if constexpr (8 * K == M) {
+        return INV ? cpx<R>{(d.x - d.y) * c8, (d.x + d.y) * c8} : cpx<R>{(d.x + d.y) * c8, (d.y - d.x) * c8};
+    } else if constexpr (8 * K == 3 * M) {
+        return INV ? cpx<R>{-(d.x + d.y) * c8, (d.x - d.y) * c8} : cpx<R>{(d.y - d.x) * c8, -(d.x + d.y) * c8};
+    } else {
+        constexpr R wr = (R) root64_re(K * (64 / M));
+        constexpr R wi = (R) (INV ? -root64_im(K * (64 / M)) : root64_im(K * (64 / M)));
+        return cpx<R>{d.x * wr - d.y * wi, d.x * wi + d.y * wr};
+    }
+}
+
+template<typename R, bool INV, int M, int G, int... K>
+__device__ __forceinline__ void dif_group(cpx<R> (&v)[32], std::integer_sequence<int, K...>) {
+    (([&] {
+         const cpx<R> u = v[G + K] + v[G + K + M / 2];
+         const cpx<R> d = v[G + K] - v[G + K + M / 2];
+         v[G + K] = u;
+         v[G + K + M / 2] = mul_root<R, INV, M, K>(d);
+     }()),
+     ...);
+}
+template<typename R, bool INV, int M, int BASE, int... G>
+__device__ __forceinline__ void dif_stage(cpx<R> (&v)[32], std::integer_sequence<int, G...>) {
+    (dif_group<R, INV, M, BASE + G * M>(v, std::make_integer_sequence<int, M / 2>{}), ...);
+}
+// N-point DFT (N = 2 .. 32) of v[BASE .. BASE+N), natural order in; v[BASE + p] returns bin brev(p, log2 N)
+template<typename R, bool INV, int N, int BASE = 0>
+__device__ __forceinline__ void dft_n(cpx<R> (&v)[32]) {
+    if constexpr (N >= 32) dif_stage<R, INV, 32, BASE>(v, std::make_integer_sequence<int, N / 32>{});
+    if constexpr (N >= 16) dif_stage<R, INV, 16, BASE>(v, std::make_integer_sequence<int, N / 16>{});
+    if constexpr (N >= 8)  dif_stage<R, INV, 8, BASE>(v, std::make_integer_sequence<int, N / 8>{});
+    if constexpr (N >= 4)  dif_stage<R, INV, 4, BASE>(v, std::make_integer_sequence<int, N / 4>{});
+    dif_stage<R, INV, 2, BASE>(v, std::make_integer_sequence<int, N / 2>{});
+}
+template<typename R, bool INV, int N, int... I>
+__device__ __forceinline__ void dft_columns(cpx<R> (&v)[32], std::integer_sequence<int, I...>) {
+    (dft_n<R, INV, N, I * N>(v), ...);
+}
+
+// LDS-only barrier: does not wait for outstanding global loads / stores
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// Buffer accesses: voff (VGPR, bytes) + soff (SGPR / literal, bytes) against a wave-uniform descriptor.
+// Out-of-range lanes read zero and their stores are dropped, which is how a partially filled last
+// group and the "no such line" waves are handled (num_records = 0).
+__device__ __forceinline__ cpx<float> buf_load(__amdgpu_buffer_rsrc_t r, int voff, int soff, float) {
+    const f2 q = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+    return cpx<float>{q.x, q.y};
+}
+__device__ __forceinline__ cpx<double> buf_load(__amdgpu_buffer_rsrc_t r, int voff, int soff, double) {
+    const d2 q = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    return cpx<double>{q.x, q.y};
+}
+// real sample widened to complex (dsc_fft on real input casts first: dsc.cpp:1984-1988)
+__device__ __forceinline__ cpx<float> buf_load_real(__amdgpu_buffer_rsrc_t r, int voff, int soff, float) {
+    return cpx<float>{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0)), 0.0f};
+}
+__device__ __forceinline__ cpx<double> buf_load_real(__amdgpu_buffer_rsrc_t r, int voff, int soff, double) {
+    return cpx<double>{__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0)), 0.0};
+}
+__device__ __forceinline__ void buf_store(cpx<float> a, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, f2{a.x, a.y}), r, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_store(cpx<double> a, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, d2{a.x, a.y}), r, voff, soff, 0);
+}
+
+}  // namespace

@@ -82,6 +82,13 @@ void   dsc_launch_rfft256k_f64(const double *x, void *X, long long rows, void *w
 void   dsc_launch_irfft256k_f64(const void *X, double *x, long long rows, void *work, const void *aux, const void *tw_real,
                                 int n_cu, hipStream_t stream);
 
+// two-pass version (fft_r2c_256k_f64_2pass.hip): rows kernel + column kernel with the real pass fused; needs only the
+// plan's own tables (tw_full: W_L^k, k < L; tw_real: W_{2L}^k, k <= L)
+void   dsc_launch_rfft256k_f64_2pass(const double *x, void *X, long long rows, void *work, const void *tw_full, const void *tw_real,
+                                     hipStream_t stream);
+void   dsc_launch_irfft256k_f64_2pass(const void *X, double *x, long long rows, void *work, const void *tw_full, const void *tw_real,
+                                      hipStream_t stream);
+
 // ---- register-resident transforms of contiguous full lines, complex length 256 .. 16384 (f32, f64; f32 C2C also 32768)
 // (fft_regs_mid.hip).  in / out: [n_lines][L] complex (C2C), [n_lines][2L] reals -> [n_lines][L+1] bins
 // (R2C_PACKED) or the converse (C2R_PACKED).  tw_full: W_L^k, k < L; tw_real: W_{2L}^k, k <= L.
