@@ -16,7 +16,7 @@ N = 65536
 def dsc():
     import dsc_amd
     try:
-        dsc_amd.init(12 << 30, 4 << 30)
+        dsc_amd.init(14 << 30, 5 << 30)
     except RuntimeWarning:
         pass
     yield dsc_amd
@@ -269,3 +269,71 @@ def test_mid_size_register_path_f64(dsc, n):
         zb = dsc.ifft(Z)
         assert dsc.last_fft_path() == 'regs_mid'
         assert rel_l2(zb.numpy(), z) <= 1e-14
+
+
+def test_full_size_filter_config3(dsc):
+    """BASELINE config 3 at full size ([4096, 65536] f32, fused rfft * H -> irfft): known answers that hold for
+    every row (identity filter, phase ramp = circular shift), linearity, and sampled rows against the
+    three-operator composition and the CPU oracle."""
+    from oracle import port
+    rows = 4096
+    rng = np.random.default_rng(33)
+    blk = rng.standard_normal((256, N)).astype(np.float32)
+    scale = (1.0 + np.arange(rows) % 7).astype(np.float32)
+    s = np.tile(blk, (rows // 256, 1)) * scale[:, None]
+    ts = dsc.from_numpy(s)
+    k = np.arange(N // 2 + 1)
+    # identity
+    y = dsc.filter_fft(ts, dsc.from_numpy(np.ones(N // 2 + 1, np.complex64)))
+    assert dsc.last_fft_path() == 'filter_64k_regs'
+    assert rel_l2(y.numpy(), s) <= 1e-6
+    # phase ramp: H[k] = exp(-2 pi i k d / N)  ->  y[n] = s[(n - d) mod N] on every row
+    d = 1234
+    H = np.exp(-2j * np.pi * k * d / N).astype(np.complex64)
+    yh = dsc.filter_fft(ts, dsc.from_numpy(H)).numpy()
+    assert rel_l2(yh, np.roll(s, d, axis=1)) <= 2e-6
+    # a real filter (low-pass taps): sampled rows against the composition and the oracle
+    taps = np.zeros(N, np.float32)
+    taps[:537] = np.hamming(537) * np.sinc((np.arange(537) - 268) * 0.2) * 0.2
+    Hl = port.rfft(taps)
+    tH = dsc.from_numpy(Hl)
+    yl = dsc.filter_fft(ts, tH).numpy()
+    comp = dsc.irfft(dsc.rfft(ts) * tH).numpy()
+    assert rel_l2(yl, comp) <= 2e-6
+    for r in (0, 1777, rows - 1):
+        want = port.irfft(port.mul(port.rfft(s[r]), Hl))
+        assert_close(yl[r], want, what=f'filter row {r}')
+    # homogeneity across the batch: row r is scale[r] / scale[r % 256] times row r % 256
+    base = yl[np.arange(rows) % 256]
+    ratio = (scale / scale[np.arange(rows) % 256])[:, None]
+    assert rel_l2(yl, base * ratio) <= 2e-6
+
+
+def test_full_size_f64_config5(dsc):
+    """BASELINE config 5 at full size ([2048, 262144] f64): sampled rows against the oracle (1e-12), Parseval and
+    round trip on every row, homogeneity across the batch."""
+    from oracle import port
+    n, rows = 262144, 2048
+    rng = np.random.default_rng(99)
+    blk = rng.standard_normal((64, n))
+    scale = 1.0 + (np.arange(rows) % 5) * 0.25
+    x = np.tile(blk, (rows // 64, 1)) * scale[:, None]
+    tx = dsc.from_numpy(x)
+    X = dsc.rfft(tx)
+    assert dsc.last_fft_path() == 'r2c_256k_f64_regs'
+    Xh = X.numpy()
+    assert Xh.shape == (rows, n // 2 + 1)
+    for r in (0, 1031, rows - 1):
+        assert_close(Xh[r], port.rfft(x[r]), what=f'f64 full-size row {r}')
+    assert np.all(Xh[:, 0].imag == 0) and np.all(Xh[:, -1].imag == 0)
+    e_t = np.sum(x * x, axis=1)
+    p = Xh.real ** 2 + Xh.imag ** 2
+    e_f = (p[:, 0] + p[:, -1] + 2 * np.sum(p[:, 1:-1], axis=1)) / n
+    assert np.max(np.abs(e_f - e_t) / e_t) < 1e-13
+    idx = np.arange(rows) % 64
+    assert rel_l2(Xh, Xh[idx] * (scale / scale[idx])[:, None]) <= 1e-15
+    del p
+    back = dsc.irfft(X)
+    assert dsc.last_fft_path() == 'c2r_256k_f64_regs'
+    bh = back.numpy()
+    assert rel_l2(bh, x) <= 1e-14 and np.max(np.abs(bh - x)) < 1e-12
