@@ -431,10 +431,14 @@ __device__ __forceinline__ void inverse_prepass(cf (&v)[32], cf y_last, const f2
     // Column 0 pairs row a with row 32 - a of itself and row 0 with bin M.  Shifting its rows
     // 17..31 down by one (bin M into row 31) turns that into the general "row a with row 31 - a
     // of the partner" with itself as partner.
+    // The shift is done in two parts, each right before the batch that needs it: batch 0 (rows 0..7 with 31..24)
+    // then depends only on rows 0..7, 24..31 and bin M — the loads the pipeline issues FIRST — and starts while
+    // rows 8..23 are still in flight.
     const cf y_mid = v[16];                                // bin M/2 pairs with itself
+    const cf row24 = v[24];
     if (wave == 0) {
 #pragma unroll
-        for (int r = 16; r < 31; ++r) v[r] = lane == 0 ? v[r + 1] : v[r];
+        for (int r = 24; r < 31; ++r) v[r] = lane == 0 ? v[r + 1] : v[r];
         v[31] = lane == 0 ? y_last : v[31];
         if (lane == 0) { v[0].y = 0.f; v[31].y = 0.f; }    // dsc_fft.h:227-228 reads the real parts only
     }
@@ -442,6 +446,11 @@ __device__ __forceinline__ void inverse_prepass(cf (&v)[32], cf y_last, const f2
     const cf wq_base = cf{0.5f * kScale * wpre.y, 0.5f * kScale * wpre.x};      // (i/2) conj(W^c) / M
 #pragma unroll
     for (int half = 0; half < 2; ++half) {                 // two batches of 8 pairs: VGPR budget
+        if (half == 1 && wave == 0) {                      // second part of the column-0 shift: rows 16..23
+#pragma unroll
+            for (int r = 16; r < 23; ++r) v[r] = lane == 0 ? v[r + 1] : v[r];
+            v[23] = lane == 0 ? row24 : v[23];
+        }
         cf q[8], zm[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -519,6 +528,17 @@ __device__ __forceinline__ void unzip_rows(cf (&v)[32]) {
     for (int a = 0; a < 32; ++a) v[a] = nxt[a];
 }
 
+// The inverse kernel's pipelined loads: even registers 0..14 = rows 0..7, even 16..30 = rows 24..31, odd = rows 8..23
+__device__ __forceinline__ void unzip_rows_outer_first(cf (&v)[32]) {
+    cf nxt[32];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) { nxt[a] = v[2 * a]; nxt[24 + a] = v[16 + 2 * a]; }
+#pragma unroll
+    for (int a = 8; a < 24; ++a) nxt[a] = v[2 * (a - 8) + 1];
+#pragma unroll
+    for (int a = 0; a < 32; ++a) v[a] = nxt[a];
+}
+
 // ------------------------------------------------------------------------------------------
 // inverse: X [batch][32769] c32  ->  x [batch][65536] f32        (dsc_irfft, dsc_fft.h:194-236)
 //
@@ -567,17 +587,20 @@ __global__ __launch_bounds__(1024) void irfft64k_kernel(const f2 *__restrict__ X
         const int t4 = thread_id(wave_sgpr);
         const int c = column_of(t4 >> 6, t4 & 63);
         staged_time_store(v, plane, rout, wave_sgpr, [&](bool first_half) {
+            // consumption order of the pre-pass: bin M and rows 0..7, 24..31 first (even registers), rows 8..23 second (odd)
             if (first_half) {
-#pragma unroll
-                for (int a = 0; a < 16; ++a) v[2 * a] = load_c_cached(rnext, c * 8, a * 8192);               // rows 0..15
-            } else {
-#pragma unroll
-                for (int a = 16; a < 32; ++a) v[2 * (a - 16) + 1] = load_c_cached(rnext, c * 8, a * 8192);   // rows 16..31
                 y_last = cf{0.f, 0.f};
                 if (c == 0) y_last = load_c_cached(rnext, kM * 8, 0);
+#pragma unroll
+                for (int a = 0; a < 8; ++a) v[2 * a] = load_c_cached(rnext, c * 8, a * 8192);                // rows 0..7
+#pragma unroll
+                for (int a = 24; a < 32; ++a) v[2 * (a - 16)] = load_c_cached(rnext, c * 8, a * 8192);       // rows 24..31
+            } else {
+#pragma unroll
+                for (int a = 8; a < 24; ++a) v[2 * (a - 8) + 1] = load_c_cached(rnext, c * 8, a * 8192);     // rows 8..23
             }
         });
-        unzip_rows(v);
+        unzip_rows_outer_first(v);
     }
 }
 
