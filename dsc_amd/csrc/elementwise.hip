@@ -50,6 +50,13 @@ void cast_from(const void *in, void *out, int out_dtype, long long ne, dim3 grid
     }
 }
 
+inline dim3 stream_grid(long long ne) {
+    long long blocks = (ne + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;        // 8 blocks per CU, grid-stride beyond that
+    if (blocks < 1) blocks = 1;
+    return dim3((unsigned) blocks);
+}
+
 // add_op / sub_op / mul_op / div_op: dsc_ops.h:46-90
 template<typename T, int OP>
 __device__ __forceinline__ T apply(T a, T b) {
@@ -99,10 +106,33 @@ __global__ void binary_kernel(const T *a, const T *b, T *out, const dsc_bcast_ar
     }
 }
 
+// equal shapes: 16 bytes per lane and operand (V = 16 / sizeof(T) elements), the widest global access
+template<typename T, int OP>
+__global__ void binary_same_vec_kernel(const T *a, const T *b, T *out, unsigned nvec) {
+    constexpr int V = 16 / sizeof(T);
+    struct alignas(16) pack { T e[V]; };
+    const pack *pa = (const pack *) a, *pb = (const pack *) b;
+    pack *po = (pack *) out;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += gridDim.x * blockDim.x) {
+        typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+        const u4v xr = __builtin_nontemporal_load((const u4v *) (pa + i)), yr = __builtin_nontemporal_load((const u4v *) (pb + i));
+        const pack x = __builtin_bit_cast(pack, xr), y = __builtin_bit_cast(pack, yr);      // touched once: streaming policy
+        pack r;
+#pragma unroll
+        for (int j = 0; j < V; ++j) r.e[j] = apply<T, OP>(x.e[j], y.e[j]);
+        __builtin_nontemporal_store(__builtin_bit_cast(u4v, r), (u4v *) (po + i));
+    }
+}
+
 template<typename T, int OP>
 bool binary_fast(const T *pa, const T *pb, T *po, const dsc_bcast_args &g, dim3 grid, hipStream_t s) {
     if (g.a_scalar || g.b_scalar || g.fast == 0) return false;
     const unsigned ne = (unsigned) g.ne, sm = (unsigned) g.small_ne;
+    constexpr unsigned V = 16 / sizeof(T);
+    if (g.fast == 1 && V > 1 && ne % V == 0 && (((size_t) pa | (size_t) pb | (size_t) po) & 15) == 0) {
+        hipLaunchKernelGGL((binary_same_vec_kernel<T, OP>), stream_grid(ne / V), dim3(256), 0, s, pa, pb, po, ne / V);
+        return true;
+    }
     if (g.fast == 1) hipLaunchKernelGGL((binary_fast_kernel<T, OP, 1>), grid, dim3(256), 0, s, pa, pb, po, ne, sm);
     else if (g.fast == 2) hipLaunchKernelGGL((binary_fast_kernel<T, OP, 2>), grid, dim3(256), 0, s, pa, pb, po, ne, sm);
     else hipLaunchKernelGGL((binary_fast_kernel<T, OP, 3>), grid, dim3(256), 0, s, pa, pb, po, ne, sm);
@@ -160,13 +190,6 @@ void unary_typed(const void *in, void *out, int op, long long ne, dim3 grid, hip
         case 3: hipLaunchKernelGGL((unary_kernel<Tin, 3>), grid, dim3(256), 0, s, x, out, ne); break;
         default: hipLaunchKernelGGL((unary_kernel<Tin, 4>), grid, dim3(256), 0, s, x, out, ne); break;
     }
-}
-
-inline dim3 stream_grid(long long ne) {
-    long long blocks = (ne + 255) / 256;
-    if (blocks > 256 * 8) blocks = 256 * 8;        // 8 blocks per CU, grid-stride beyond that
-    if (blocks < 1) blocks = 1;
-    return dim3((unsigned) blocks);
 }
 
 }  // namespace
