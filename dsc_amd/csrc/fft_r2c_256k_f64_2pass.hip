@@ -78,7 +78,7 @@ __global__ __launch_bounds__(512, 2) void c5_rows_kernel(const C *__restrict__ i
     C u[32], v[32];
     if constexpr (!INV) {
 #pragma unroll
-        for (int m = 0; m < 32; ++m) u[m] = buf_load(rin, zoff, m * 65536, 0.0);
+        for (int m = 0; m < 32; ++m) u[m] = buf_load<kStream>(rin, zoff, m * 65536, 0.0);
         __syncthreads();
         dft_n<double, false, 32>(u);                                          // over j2' -> k2' in u[brev(k2')]
 #pragma unroll
@@ -99,10 +99,10 @@ __global__ __launch_bounds__(512, 2) void c5_rows_kernel(const C *__restrict__ i
         dft_n<double, false, 32>(v);                                          // over t -> k3 in v[brev(k3)]
         four_step_twiddle<false, true>(v, twL[j1r * rtau], twL[32 * j1r]);
 #pragma unroll
-        for (int k3 = 0; k3 < 32; ++k3) buf_store(v[brev(k3, 5)], rout, aoff, k3 * 512);
+        for (int k3 = 0; k3 < 32; ++k3) buf_store<kStream>(v[brev(k3, 5)], rout, aoff, k3 * 512);
     } else {
 #pragma unroll
-        for (int k3 = 0; k3 < 32; ++k3) v[k3] = buf_load(rin, aoff, k3 * 512, 0.0);
+        for (int k3 = 0; k3 < 32; ++k3) v[k3] = buf_load<kStream>(rin, aoff, k3 * 512, 0.0);
         __syncthreads();
         four_step_twiddle<true, false>(v, twL[j1r * rtau], twL[32 * j1r]);
         dft_n<double, true, 32>(v);                                           // over k3 -> t in v[brev(t)]
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(512, 2) void c5_rows_kernel(const C *__restrict__ i
 #pragma unroll
         for (int m = 0; m < 32; ++m) {
             const C r = u[brev(m, 5)];
-            buf_store(C{r.x * scale, r.y * scale}, rout, zoff, m * 65536);
+            buf_store<kStream>(C{r.x * scale, r.y * scale}, rout, zoff, m * 65536);
         }
     }
 }
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(512, 2) void c5_cols_kernel(const C *__restrict__ i
     C u[32], v[32];
     if constexpr (!INV) {
 #pragma unroll
-        for (int i = 0; i < 32; ++i) u[i] = buf_load(rwork, woff, i * 65536, 0.0);
+        for (int i = 0; i < 32; ++i) u[i] = buf_load<kStream>(rwork, woff, i * 65536, 0.0);
         __syncthreads();
         dft_n<double, false, 32>(u);                                          // over i -> k' in u[brev(k')]
 #pragma unroll
@@ -236,19 +236,19 @@ __global__ __launch_bounds__(512, 2) void c5_cols_kernel(const C *__restrict__ i
             C xk = C{0.5 * sx + (dx * wqx - dy * wqy), 0.5 * sy + (dx * wqy + dy * wqx)};
             if (e == 0 && col0 && t == 0) {                                   // k = 0: X[0], X[L] real (dsc_fft.h:221-225); its "partner" read is unused
                 xk = C{ax + ay, 0.0};
-                buf_store(C{ax - ay, 0.0}, rbins, kL * 16, 0);
+                buf_store<kStream>(C{ax - ay, 0.0}, rbins, kL * 16, 0);
             }
-            buf_store(xk, rbins, boff, k1 * 16384);
+            buf_store<kStream>(xk, rbins, boff, k1 * 16384);
         }
     } else {
         // ---- load the bins in the layout the forward kernel leaves them in, pre-pass (dsc_fft.h:194-228)
 #pragma unroll
         for (int e = 0; e < 32; ++e) {
             const int k1 = t + 4 * (e >> 2) + 32 * (e & 3);                   // natural k3 order: v[4 i' + k3]
-            v[e] = buf_load(rbins, boff, k1 * 16384, 0.0);
+            v[e] = buf_load<kStream>(rbins, boff, k1 * 16384, 0.0);
         }
         C ylast = C{0.0, 0.0};
-        if (col0 && t == 0) { ylast = buf_load(rbins, kL * 16, 0, 0.0); v[0].y = 0.0; }     // real parts only at k = 0 and k = L
+        if (col0 && t == 0) { ylast = buf_load<kStream>(rbins, kL * 16, 0, 0.0); v[0].y = 0.0; }     // real parts only at k = 0 and k = L
         __syncthreads();
         double bx[32];
         const stage_ptrs sp = make_stage(plane, t, ell, ellp, col0);
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(512, 2) void c5_cols_kernel(const C *__restrict__ i
         for (int k = 0; k < 32; ++k) u[k].y = rd[k * 512];
         dft_n<double, true, 32>(u);                                           // over k' -> i in u[brev(i)]
 #pragma unroll
-        for (int i = 0; i < 32; ++i) buf_store(u[brev(i, 5)], rwork, woff, i * 65536);
+        for (int i = 0; i < 32; ++i) buf_store<kStream>(u[brev(i, 5)], rwork, woff, i * 65536);
     }
 }
 

@@ -81,6 +81,12 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
     constexpr int in_pitch = MODE == DSC_MODE_C2R_PACKED ? L + 1 : L;
     constexpr int out_pitch = MODE == DSC_MODE_R2C_PACKED ? L + 1 : L;
     constexpr int IB = MODE == DSC_MODE_R2C_CAST ? (int) sizeof(R) : CB;      // bytes per input element
+    // measured per mode (tools/bench_mid.py): complex transforms gain 1-3 % from streaming both ways, the inverse real
+    // ones from streaming their (aligned) stores at L >= 2048; everything that touches rows of L + 1 bins, and the
+    // forward real transform as a whole, is faster cached (see fft_regs_common.h)
+    constexpr bool kComplex = MODE == DSC_MODE_C2C || MODE == DSC_MODE_R2C_CAST;
+    constexpr int LOADP = kComplex ? kStream : kCached;
+    constexpr int STOREP = kComplex || (MODE == DSC_MODE_C2R_PACKED && !TWO) ? kStream : kCached;
     const __amdgpu_buffer_rsrc_t rin =
         __builtin_amdgcn_make_buffer_rsrc((void *) ((const char *) in + line0 * in_pitch * IB), 0, n_valid * in_pitch * IB, 0x00020000);
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *) (out + line0 * out_pitch), 0, n_valid * out_pitch * CB, 0x00020000);
@@ -93,8 +99,8 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
     C v[32];
 #pragma unroll
     for (int j1 = 0; j1 < 32; ++j1) {                                                        // z[T j1 + t]
-        if constexpr (MODE == DSC_MODE_R2C_CAST) v[j1] = buf_load_real(rin, vin, j1 * T * IB, R{});
-        else                                     v[j1] = buf_load(rin, vin, j1 * T * CB, R{});
+        if constexpr (MODE == DSC_MODE_R2C_CAST) v[j1] = buf_load_real<LOADP>(rin, vin, j1 * T * IB, R{});
+        else                                     v[j1] = buf_load<LOADP>(rin, vin, j1 * T * CB, R{});
     }
 
     if constexpr (MODE == DSC_MODE_C2R_PACKED) {
@@ -102,7 +108,7 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
         // thread's own k = T j1 + t; b comes through the staging plane, one component at a time.
         const C wbase = tw_real[t];
         C yl = C{(R) 0, (R) 0};
-        if (t == 0) { yl = buf_load(rin, vin, L * CB, R{}); v[0].y = (R) 0; yl.y = (R) 0; }   // dsc_fft.h:227-228: real parts only at k = 0
+        if (t == 0) { yl = buf_load<LOADP>(rin, vin, L * CB, R{}); v[0].y = (R) 0; yl.y = (R) 0; }   // dsc_fft.h:227-228: real parts only at k = 0
         R dx[32];
         R *up = stage + t;                          // up[T j1]         = stage[k]
         const R *dn = stage + (L - 31 * T) - t;     // dn[T (31 - j1)]  = stage[L - k]
@@ -210,7 +216,7 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
 #pragma unroll
             for (int p = 0; p < B; ++p) {
                 const C r = v[i * B + p];
-                buf_store(C{r.x * scale, r.y * scale}, rout, vout, (T * i + COLS * brev(p, LOGB)) * CB);
+                buf_store<STOREP>(C{r.x * scale, r.y * scale}, rout, vout, (T * i + COLS * brev(p, LOGB)) * CB);
             }
     } else {
         // packed-real post-pass (dsc_fft.h:199-225), one thread per PAIR (k, L-k), k = t + T i < L/2,
@@ -247,12 +253,12 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
             C xk = C{(R) 0.5 * sx + wdx, (R) 0.5 * sy + wdy};
             C xm = C{(R) 0.5 * sx - wdx, wdy - (R) 0.5 * sy};
             if (i == 0 && t == 0) { xk.y = (R) 0; xm.y = (R) 0; }           // dsc_fft.h:221-225 stores exact zeros
-            buf_store(C{xk.x * scale, xk.y * scale}, rout, vout, T * i * CB);
-            buf_store(C{xm.x * scale, xm.y * scale}, rout, dn_voff, T * (15 - i) * CB);
+            buf_store<STOREP>(C{xk.x * scale, xk.y * scale}, rout, vout, T * i * CB);
+            buf_store<STOREP>(C{xm.x * scale, xm.y * scale}, rout, dn_voff, T * (15 - i) * CB);
         }
         if (t == 0) {                                                     // k = L/2: a = b, W_2L^{L/2} = -i
             const R ay = stage[L / 2];
-            buf_store(C{amx * scale, -ay * scale}, rout, vout, (L / 2) * CB);
+            buf_store<STOREP>(C{amx * scale, -ay * scale}, rout, vout, (L / 2) * CB);
         }
     }
 }
