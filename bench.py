@@ -103,6 +103,7 @@ def main():
                          'milliseconds of load to come back up after the host-side parity check (0 disables)')
     ap.add_argument('--batch', type=int, default=BATCH, help='rows per GPU (default: BASELINE config 2)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-kernels', action='store_true', help='skip the untimed-for-value irfft / fused-filter measurements')
     ap.add_argument('--no-allgather', action='store_true')
     ap.add_argument('--allgather-timeout', type=float, default=180.0, help='seconds the separate RCCL all-gather phase may take before it is abandoned')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (gloo for the CPU dry run)')
@@ -150,7 +151,7 @@ def main():
             import dsc_amd as dsc
             from dsc_amd import _bindings as B
             from dsc_amd.context import _get_ctx
-            dsc.init(rows * BYTES_PER_ROW + (1 << 30), 1 << 30, device=local_rank)
+            dsc.init(2 * rows * BYTES_PER_ROW + (1 << 30), 1 << 30, device=local_rank)
         ctx = _get_ctx()
         x_host = synthetic_rows(rows, rank)
         x = dsc.from_numpy(x_host)
@@ -192,6 +193,40 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if args.dry_run or args.backend == 'gloo' else 'cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- the other two kernels of the hot path on the same buffers (configs[1] irfft, configs[2] fused filter on half the
+    # batch): reported next to the metric, never part of `value`
+    if not args.dry_run and not args.no_other_kernels:
+        try:
+            back = dsc.empty((rows, N_FFT), dsc.Dtype.F32)
+            H = dsc.from_numpy(np.ones(N_FFT // 2 + 1, np.complex64))
+            half = rows // 2 if rows >= 2 else rows
+            s_half = dsc.from_numpy(x_host[:half])
+            y_half = dsc.empty((half, N_FFT), dsc.Dtype.F32)
+
+            def timed(f, n=args.steps):
+                for _ in range(max(10, args.warmup)):
+                    f()
+                dsc.synchronize()
+                B.dsc_timer_start(ctx)
+                for _ in range(n):
+                    f()
+                return B.dsc_timer_stop(ctx) / n
+
+            ms_i = timed(lambda: B.dsc_irfft(ctx, out._c_ptr, back._c_ptr, -1, -1))
+            p_i = dsc.last_fft_path()
+            ms_f = timed(lambda: B.dsc_filter_fft(ctx, s_half._c_ptr, H._c_ptr, y_half._c_ptr))
+            p_f = dsc.last_fft_path()
+            extra['other_kernels'] = {
+                'irfft': {'ms': round(ms_i, 4), 'frac_of_8TBps': round(rows * BYTES_PER_ROW / (ms_i * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          'rows': rows, 'kernel_path': p_i},
+                'fused_filter': {'ms': round(ms_f, 4), 'frac_of_8TBps': round(half * N_FFT * 8 / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                 'rows': half, 'kernel_path': p_f, 'bytes_per_sample': 8},
+                'note': 'same process, same HIP-event timer, this rank only; not included in value',
+            }
+            del back, H, s_half, y_half
+        except Exception as e:
+            extra['other_kernels'] = {'error': repr(e)[:200]}
 
     if rank == 0:
         total_samples = world * rows * N_FFT * args.steps

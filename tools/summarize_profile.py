@@ -23,7 +23,7 @@ def counter(name, sub, match):
 lines = ['# rocprofv3 summary (' + os.path.basename(out.rstrip('/')) + ')', '']
 bench = json.load(open(f'{out}/bench.json'))
 lines += ['## bench.py line (un-profiled run)', '', '```json', json.dumps(bench), '```', '']
-lines += ['## `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 500 --warmup 50 --no-cpu-baseline` (plus the untimed 100 ms clock ramp, ≈110 launches)', '']
+lines += ['## `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 500 --warmup 50 --no-cpu-baseline --no-other-kernels` (plus the untimed 100 ms clock ramp, ≈110 launches)', '']
 for f in glob.glob(f'{out}/trace/*/*_kernel_stats.csv'):
     lines += ['```csv'] + open(f).read().strip().splitlines() + ['```', '']
 avg_ns = None
