@@ -7,7 +7,8 @@
 //
 //   r2c_64k_regs / c2r_64k_regs   f32, 65536-point real transform of contiguous rows:
 //                                  register-resident, one HBM round trip (fft_r2c_64k.hip)
-//   r2c_256k_f64_regs / c2r_...    f64, 262144-point real transform: three passes (fft_r2c_256k_f64.hip)
+//   r2c_2pass_regs / c2r_2pass_... real transforms of 65536 (f64) .. 524288 points, contiguous rows: two passes over HBM,
+//                                  register-resident rows and column kernels (fft_r2c_2pass.hip)
 //   regs_mid                       contiguous full lines, complex length 256 .. 16384 (f32, f64; f32 complex
 //                                  also 32768): register-resident, one HBM round trip (fft_regs_mid.hip)
 //   generic_lds                    any axis / padding, complex length <= dsc_fft_lds_max_len: one pass (fft_generic.hip)
@@ -263,23 +264,30 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
         }
     }
 
-    // 262144-point f64 real transforms (config 5): radix-8 + register-resident 16384-point passes
-    if (!sp && packed && j.L == 131072 && inner == 1 && plan->tw_aux != nullptr) {
-        const bool fwd = j.mode == DSC_MODE_R2C_PACKED && j.in_len == 262144 && j.x->shape[j.slot] == 262144;
-        const bool inv = j.mode == DSC_MODE_C2R_PACKED && j.in_len == 131073 && j.x->shape[j.slot] == 131073;
+    // long real transforms of contiguous full rows (config 5 = f64 N = 262144): two passes over HBM, rows kernel + column
+    // kernel with the real pass fused (fft_r2c_2pass.hip).  DSC_C5_3PASS=1 selects the first, three-pass version of the
+    // f64 262144-point case for A/B.
+    static const bool two_pass_off = getenv("DSC_NO_TWO_PASS") != nullptr;        // A/B aid (tools/bench_mid.py)
+    if (packed && inner == 1 && !two_pass_off && dsc_fft_two_pass_supports(j.L, sp)) {
+        const int L = j.L;
+        const bool fwd = j.mode == DSC_MODE_R2C_PACKED && j.in_len == 2 * L && j.x->shape[j.slot] == 2 * L;
+        const bool inv = j.mode == DSC_MODE_C2R_PACKED && j.in_len == L + 1 && j.x->shape[j.slot] == L + 1;
         if (fwd || inv) {
-            const size_t row_bytes = (size_t) 131072 * 16;
+            static const bool three_pass_env = getenv("DSC_C5_3PASS") != nullptr;
+            const bool three_pass = three_pass_env && !sp && L == 131072 && plan->tw_aux != nullptr;
+            const size_t csz = sp ? 8 : 16;
+            const size_t row_bytes = (size_t) L * csz;
+            const size_t real_row = (size_t) 2 * L * (csz / 2), bins_row = (size_t) (L + 1) * csz;
             ctx->scratch.reset();
             long long chunk = (long long) ((ctx->scratch.capacity() - DSC_DEVICE_ALIGN) / row_bytes);
-            if (chunk < 1) DSC_LOG_FATAL("scratch arena too small: a 262144-point f64 transform needs 2 MB of scratch per row");
-            static const bool three_pass = getenv("DSC_C5_3PASS") != nullptr;          // A/B aid: the first (three-pass) version
+            if (chunk < 1) DSC_LOG_FATAL("scratch arena too small: a %d-point transform needs %.1f MB of scratch per row", 2 * L, row_bytes / 1048576.);
             {
-                // chunk of rows per launch sequence: as many as the scratch arena holds (the two-pass kernels lose 15 % when
-                // cut into 64-row launches; the three-pass version gained 4-9 % from keeping its work buffer in the MALL)
+                // rows per launch sequence: as many as the scratch arena holds (the two-pass kernels lose 15 % when cut into
+                // 64-row launches; the three-pass version gained 4-9 % from keeping its work buffer in the Infinity Cache)
                 static long long cap_rows = -1;
                 if (cap_rows < 0) {
                     const char *e = getenv("DSC_C5_CHUNK_ROWS");
-                    cap_rows = e ? atoll(e) : (three_pass ? 64 : (1LL << 40));
+                    cap_rows = e ? atoll(e) : (three_pass_env ? 64 : (1LL << 40));
                     if (cap_rows < 1) cap_rows = 1;
                 }
                 if (chunk > cap_rows) chunk = cap_rows;
@@ -288,23 +296,16 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
             char *work = ctx->scratch.alloc((size_t) chunk * row_bytes);
             for (long long q = 0; q < n_lines; q += chunk) {
                 const long long nl = n_lines - q < chunk ? n_lines - q : chunk;
-                if (!three_pass) {
-                    if (fwd)
-                        dsc_launch_rfft256k_f64_2pass((const double *) j.x->data + q * 262144, (char *) j.out->data + (size_t) q * 131073 * 16,
-                                                      nl, work, plan->tw_full, plan->tw_real, ctx->stream);
-                    else
-                        dsc_launch_irfft256k_f64_2pass((const char *) j.x->data + (size_t) q * 131073 * 16, (double *) j.out->data + q * 262144,
-                                                       nl, work, plan->tw_full, plan->tw_real, ctx->stream);
-                    continue;
-                }
-                if (fwd)
-                    dsc_launch_rfft256k_f64((const double *) j.x->data + q * 262144, (char *) j.out->data + (size_t) q * 131073 * 16, nl,
-                                            work, plan->tw_aux, plan->tw_real, ctx->n_cu, ctx->stream);
+                const char *src = (const char *) j.x->data + (size_t) q * (fwd ? real_row : bins_row);
+                char *dst = (char *) j.out->data + (size_t) q * (fwd ? bins_row : real_row);
+                if (!three_pass)
+                    dsc_launch_rfft_two_pass(src, dst, nl, L, inv, sp, work, plan->tw_full, plan->tw_real, ctx->stream);
+                else if (fwd)
+                    dsc_launch_rfft256k_f64((const double *) src, dst, nl, work, plan->tw_aux, plan->tw_real, ctx->n_cu, ctx->stream);
                 else
-                    dsc_launch_irfft256k_f64((const char *) j.x->data + (size_t) q * 131073 * 16, (double *) j.out->data + q * 262144, nl,
-                                             work, plan->tw_aux, plan->tw_real, ctx->n_cu, ctx->stream);
+                    dsc_launch_irfft256k_f64(src, (double *) dst, nl, work, plan->tw_aux, plan->tw_real, ctx->n_cu, ctx->stream);
             }
-            ctx->last_fft_path = fwd ? "r2c_256k_f64_regs" : "c2r_256k_f64_regs";
+            ctx->last_fft_path = fwd ? "r2c_2pass_regs" : "c2r_2pass_regs";
             return;
         }
     }

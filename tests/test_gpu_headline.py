@@ -178,7 +178,7 @@ def test_f64_262144_register_path(dsc):
     for rows in (1, 3, 37):
         x = rng.standard_normal((rows, 262144))
         X = dsc.rfft(dsc.from_numpy(x))
-        assert dsc.last_fft_path() == 'r2c_256k_f64_regs'
+        assert dsc.last_fft_path() == 'r2c_2pass_regs'
         got = X.numpy()
         for r in sorted({0, rows - 1}):
             assert_close(got[r], port.rfft(x[r]), what=f'f64 rfft row {r}/{rows}')
@@ -187,7 +187,7 @@ def test_f64_262144_register_path(dsc):
         Xq = got.copy()
         Xq[:, 0] += 2j                                     # imaginary parts of bins 0 and n are ignored (dsc_fft.h:227-228)
         back = dsc.irfft(dsc.from_numpy(Xq))
-        assert dsc.last_fft_path() == 'c2r_256k_f64_regs'
+        assert dsc.last_fft_path() == 'c2r_2pass_regs'
         bh = back.numpy()
         assert_close(bh[0], port.irfft(Xq[0]), what='f64 irfft')
         assert rel_l2(bh, x) <= 1e-14
@@ -320,7 +320,7 @@ def test_full_size_f64_config5(dsc):
     x = np.tile(blk, (rows // 64, 1)) * scale[:, None]
     tx = dsc.from_numpy(x)
     X = dsc.rfft(tx)
-    assert dsc.last_fft_path() == 'r2c_256k_f64_regs'
+    assert dsc.last_fft_path() == 'r2c_2pass_regs'
     Xh = X.numpy()
     assert Xh.shape == (rows, n // 2 + 1)
     for r in (0, 1031, rows - 1):
@@ -334,6 +334,32 @@ def test_full_size_f64_config5(dsc):
     assert rel_l2(Xh, Xh[idx] * (scale / scale[idx])[:, None]) <= 1e-15
     del p
     back = dsc.irfft(X)
-    assert dsc.last_fft_path() == 'c2r_256k_f64_regs'
+    assert dsc.last_fft_path() == 'c2r_2pass_regs'
     bh = back.numpy()
     assert rel_l2(bh, x) <= 1e-14 and np.max(np.abs(bh - x)) < 1e-12
+
+
+@pytest.mark.parametrize('dt,n', [(np.float32, 131072), (np.float32, 262144), (np.float32, 524288),
+                                  (np.float64, 65536), (np.float64, 131072), (np.float64, 524288)])
+def test_two_pass_long_transforms(dsc, dt, n):
+    """Real lengths beyond one CU's registers (fft_r2c_2pass.hip: rows kernel + column kernel with the real pass fused),
+    every L1 = n / 2048 in {32, 64, 128, 256}, f32 and f64 (f64 262144 = config 5 has its own tests)."""
+    from oracle import port
+    rng = np.random.default_rng(n + (1 if dt == np.float64 else 0))
+    exact = 1e-6 if dt == np.float32 else 1e-14
+    for rows in (1, 5):
+        x = rng.standard_normal((rows, n)).astype(dt)
+        X = dsc.rfft(dsc.from_numpy(x))
+        assert dsc.last_fft_path() == 'r2c_2pass_regs'
+        got = X.numpy()
+        assert_close(got[rows - 1], port.rfft(x[rows - 1]), what=f'rfft {np.dtype(dt).name} n={n}')
+        assert rel_l2(got, np.fft.rfft(x.astype(np.float64), axis=-1)) <= exact
+        assert np.all(got[:, 0].imag == 0) and np.all(got[:, -1].imag == 0)
+        Xq = got.copy()
+        Xq[:, 0] += 2j                                     # ignored by dsc_fft.h:227-228
+        Xq[:, -1] -= 3j
+        back = dsc.irfft(dsc.from_numpy(Xq))
+        assert dsc.last_fft_path() == 'c2r_2pass_regs'
+        bh = back.numpy()
+        assert_close(bh[0], port.irfft(Xq[0]), what=f'irfft {np.dtype(dt).name} n={n}')
+        assert rel_l2(bh, x) <= exact

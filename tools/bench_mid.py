@@ -1,5 +1,5 @@
 """Times rfft / irfft / fft of contiguous rows at mid sizes (2 GiB of real samples per case).
-usage: python tools/bench_mid.py [n ...]      DSC_NO_REGS_MID=1 selects the generic kernels."""
+usage: python tools/bench_mid.py [n ...]      DSC_NO_REGS_MID=1 / DSC_NO_TWO_PASS=1 select the generic kernels."""
 import sys
 sys.path.insert(0, '.')
 import numpy as np
@@ -9,7 +9,7 @@ from dsc_amd.context import _get_ctx
 
 f64 = '--f64' in sys.argv
 sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [512, 1024, 2048, 4096, 8192, 16384, 32768, 65536]
-dsc.init(16 << 30, 2 << 30)
+dsc.init(16 << 30, 5 << 30)
 ctx = _get_ctx()
 
 
