@@ -10,5 +10,7 @@ from .dtype import Dtype
 from .tensor import (Tensor, absolute, add, angle, conj, imag, real, empty, fft, fftfreq, filter_fft, from_numpy, ifft, irfft, max, mean, min, mul, plan_fft, rfft, rfftfreq, sub, sum, transpose,
                      true_div)
 
-__all__ = ['init', 'clear', 'shutdown', 'synchronize', 'used_mem', 'last_fft_path', 'Dtype', 'Tensor', 'empty',
+from .profiler import profile, start_recording, stop_recording  # noqa: E402
+
+__all__ = ['profile', 'start_recording', 'stop_recording', 'init', 'clear', 'shutdown', 'synchronize', 'used_mem', 'last_fft_path', 'Dtype', 'Tensor', 'empty',
            'from_numpy', 'mul', 'add', 'sub', 'true_div', 'absolute', 'angle', 'conj', 'real', 'imag', 'sum', 'mean', 'max', 'min', 'plan_fft', 'fft', 'ifft', 'rfft', 'irfft', 'filter_fft', 'transpose', 'fftfreq', 'rfftfreq']

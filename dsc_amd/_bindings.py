@@ -131,6 +131,9 @@ def dsc_transpose(ctx, x, *axes):
 
 dsc_fftfreq = _sig('dsc_fftfreq', _DscTensor_p, _DscCtx, c_int, c_double, c_uint8)
 dsc_rfftfreq = _sig('dsc_rfftfreq', _DscTensor_p, _DscCtx, c_int, c_double, c_uint8)
+dsc_traces_record = _sig('dsc_traces_record', None, _DscCtx, c_bool)
+dsc_dump_traces = _sig('dsc_dump_traces', None, _DscCtx, c_char_p)
+dsc_clear_traces = _sig('dsc_clear_traces', None, _DscCtx)
 dsc_set_device = _sig('dsc_set_device', c_int, c_int)
 dsc_copy_from_host = _sig('dsc_copy_from_host', None, _DscCtx, _DscTensor_p, c_void_p, c_size_t)
 dsc_copy_to_host = _sig('dsc_copy_to_host', None, _DscCtx, _DscTensor_p, c_void_p, c_size_t)

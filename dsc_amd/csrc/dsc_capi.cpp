@@ -69,6 +69,9 @@ extern "C" void dsc_ctx_free(dsc_ctx *ctx) {
     if (ctx == nullptr) return;
     HIP_CHECK(hipSetDevice(ctx->device));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    dsc_trace_release(ctx);
+    for (hipEvent_t e : ctx->tracer.free_events) HIP_CHECK(hipEventDestroy(e));
+    if (ctx->tracer.based) HIP_CHECK(hipEventDestroy(ctx->tracer.base_ev));
     DSC_LOG_INFO("freeing context %p: main mem %ldMB, scratch mem %ldMB", (void *) ctx,
                  (long) (ctx->main.capacity() >> 20), (long) (ctx->scratch.capacity() >> 20));
     release_headers(ctx);
@@ -243,6 +246,7 @@ static dsc_tensor *cast_into(dsc_ctx *ctx, dsc_tensor *x, dsc_dtype new_dtype, b
 // dsc.cpp:587-597
 extern "C" dsc_tensor *dsc_cast(dsc_ctx *ctx, dsc_tensor *x, dsc_dtype new_dtype) {
     DSC_ASSERT(x != nullptr);
+    DSC_TRACE_OP(ctx, "op;cast", x, nullptr, (int) new_dtype, 0);
     DSC_ASSERT(new_dtype < 4);
     return cast_into(ctx, x, new_dtype, false);
 }
@@ -267,6 +271,8 @@ static const dsc_dtype k_promote[4][4] = {      // dsc_dtype.h:73-78
 static dsc_tensor *binary_entry(dsc_ctx *ctx, dsc_tensor *xa, dsc_tensor *xb, dsc_tensor *out, int op) {
     DSC_ASSERT(xa != nullptr);
     DSC_ASSERT(xb != nullptr);
+    static const char *names[] = {"dsc_add", "dsc_sub", "dsc_mul", "dsc_div"};
+    dsc_trace_scope trace__(ctx, names[op], "op;binary", xa, xb);
     int shape[DSC_MAX_DIMS];
     for (int i = 0; i < DSC_MAX_DIMS; ++i) {       // can_broadcast, dsc.cpp:1174-1184
         DSC_ASSERT(xa->shape[i] == xb->shape[i] || xa->shape[i] == 1 || xb->shape[i] == 1);
@@ -332,6 +338,8 @@ extern "C" dsc_tensor *dsc_div(dsc_ctx *ctx, dsc_tensor *xa, dsc_tensor *xb, dsc
 static dsc_dtype as_real(dsc_dtype t) { return dsc_is_single(t) ? DSC_F32 : DSC_F64; }
 
 static dsc_tensor *unary_entry(dsc_ctx *ctx, const dsc_tensor *x, dsc_tensor *out, int op, dsc_dtype out_dtype) {
+    static const char *names[] = {"dsc_abs", "dsc_angle", "dsc_conj", "dsc_real", "dsc_imag"};
+    dsc_trace_scope trace__(ctx, names[op], "op;unary", x);
     if (out == nullptr) {
         out = dsc_new_tensor(ctx, x->n_dim, &x->shape[DSC_MAX_DIMS - x->n_dim], out_dtype, nullptr);
     } else {                                          // dsc.cpp:1490-1494
@@ -378,6 +386,8 @@ extern "C" dsc_tensor *dsc_imag(dsc_ctx *ctx, const dsc_tensor *x) {
 // user-supplied `out` can observe; here those slots are 1 and such an `out` is accepted.
 static dsc_tensor *reduce_entry(dsc_ctx *ctx, const dsc_tensor *x, dsc_tensor *out, int axis, bool keep_dims, int op) {
     DSC_ASSERT(x != nullptr);
+    static const char *names[] = {"dsc_sum", "dsc_mean", "dsc_max", "dsc_min"};
+    dsc_trace_scope trace__(ctx, names[op], "op;unary", x, nullptr, 0, axis);
     const int slot = dsc_axis_slot(x, axis);
     DSC_ASSERT(slot >= 0 && slot < DSC_MAX_DIMS);
 

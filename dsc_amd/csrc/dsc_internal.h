@@ -121,6 +121,23 @@ struct dsc_fft_plan {
     char *block;              // arena block holding the above
 };
 
+// Tracing (dsc.h:159-168, dsc_tracing.h): one record per operator call while recording is on — host begin / end
+// timestamps plus a pair of HIP events on the context's stream, so that the dump shows both the (asynchronous) API call
+// and the kernels it enqueued.  tracing.cpp.
+struct dsc_trace_rec {
+    char name[32], cat[16], args[224];
+    unsigned long long ts_b, ts_e;       // host, microseconds
+    hipEvent_t ev_b, ev_e;
+};
+struct dsc_tracer {
+    bool recording = false;
+    bool based = false;
+    unsigned long long base_ts = 0;      // host time of base_ev
+    hipEvent_t base_ev = nullptr;
+    std::vector<dsc_trace_rec> recs;
+    std::vector<hipEvent_t> free_events;
+};
+
 struct dsc_ctx {
     int device;
     hipStream_t stream;
@@ -133,8 +150,25 @@ struct dsc_ctx {
     std::vector<dsc_tensor *> tensor_pool;             // recycled headers
     const char *last_fft_path;
     int n_cu;
+    dsc_tracer tracer;
 };
 
 // internal helpers shared by the C-ABI translation units
 dsc_tensor *dsc_new_tensor_in(dsc_ctx *ctx, int n_dim, const int *shape, dsc_dtype dtype,
                               dsc_tensor_buffer *buffer, bool in_scratch);
+
+// RAII scope placed at the top of an operator entry point: no cost beyond a branch unless recording.
+void dsc_trace_begin(dsc_ctx *ctx, const char *name, const char *cat, const dsc_tensor *a, const dsc_tensor *b, int i0, int i1);
+void dsc_trace_end(dsc_ctx *ctx, size_t index);
+void dsc_trace_release(dsc_ctx *ctx);
+struct dsc_trace_scope {
+    dsc_ctx *ctx;
+    size_t index;
+    bool on;
+    dsc_trace_scope(dsc_ctx *c, const char *name, const char *cat, const dsc_tensor *a = nullptr, const dsc_tensor *b = nullptr,
+                    int i0 = 0, int i1 = 0) : ctx(c), index(0), on(c != nullptr && c->tracer.recording) {
+        if (on) { index = c->tracer.recs.size(); dsc_trace_begin(c, name, cat, a, b, i0, i1); on = c->tracer.recs.size() > index; }
+    }
+    ~dsc_trace_scope() { if (on) dsc_trace_end(ctx, index); }
+};
+#define DSC_TRACE_OP(ctx, cat, ...) dsc_trace_scope trace__((ctx), __func__, (cat), ##__VA_ARGS__)

@@ -349,6 +349,7 @@ static dsc_tensor *make_out(dsc_ctx *ctx, const dsc_tensor *x, dsc_tensor *out, 
 // dsc.cpp:2009-2071
 static dsc_tensor *internal_fft(dsc_ctx *ctx, const dsc_tensor *x, dsc_tensor *out, int n, int axis, bool forward) {
     DSC_ASSERT(x != nullptr);
+    dsc_trace_scope trace__(ctx, forward ? "dsc_fft" : "dsc_ifft", "op;fft", x, nullptr, n, axis);
     const int slot = dsc_axis_slot(x, axis);
     DSC_ASSERT(slot >= 0 && slot < DSC_MAX_DIMS);
     const int x_n = x->shape[slot];
@@ -375,6 +376,7 @@ static dsc_tensor *internal_fft(dsc_ctx *ctx, const dsc_tensor *x, dsc_tensor *o
 // dsc.cpp:2173-2244
 static dsc_tensor *internal_rfft(dsc_ctx *ctx, const dsc_tensor *x, dsc_tensor *out, int n, int axis, bool forward) {
     DSC_ASSERT(x != nullptr);
+    dsc_trace_scope trace__(ctx, forward ? "dsc_rfft" : "dsc_irfft", "op;fft", x, nullptr, n, axis);
     const int slot = dsc_axis_slot(x, axis);
     DSC_ASSERT(slot >= 0 && slot < DSC_MAX_DIMS);
     const int x_n = x->shape[slot];
@@ -435,6 +437,7 @@ extern "C" dsc_tensor *dsc_irfft(dsc_ctx *ctx, const dsc_tensor *x, dsc_tensor *
 // three-operator composition the reference's users write by hand.
 extern "C" dsc_tensor *dsc_filter_fft(dsc_ctx *ctx, const dsc_tensor *s, const dsc_tensor *H, dsc_tensor *out) {
     DSC_ASSERT(s != nullptr && H != nullptr);
+    DSC_TRACE_OP(ctx, "op;fft", s, H);
     DSC_ASSERT(dsc_is_complex(H->dtype));
     const int bins = H->shape[DSC_MAX_DIMS - 1];
     DSC_ASSERT(H->ne == bins && bins >= 2);

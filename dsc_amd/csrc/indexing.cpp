@@ -85,6 +85,7 @@ static dsc_region region_of(const dsc_tensor *x, int n_slices, const dsc_slice *
 // dsc.cpp:832-866
 extern "C" dsc_tensor *dsc_tensor_get_idx(dsc_ctx *ctx, const dsc_tensor *x, int indexes, ...) {
     DSC_ASSERT(x != nullptr);
+    DSC_TRACE_OP(ctx, "idx;get", x);
     DSC_ASSERT((unsigned) indexes <= DSC_MAX_DIMS);
     if (indexes > x->n_dim) DSC_LOG_FATAL("too many indexes");
     DSC_ASSERT(indexes >= 1);                       // the reference reads stride[-1] for zero indexes
@@ -117,6 +118,7 @@ extern "C" dsc_tensor *dsc_tensor_get_idx(dsc_ctx *ctx, const dsc_tensor *x, int
 // dsc.cpp:935-992
 extern "C" dsc_tensor *dsc_tensor_get_slice(dsc_ctx *ctx, const dsc_tensor *x, int slices, ...) {
     DSC_ASSERT(x != nullptr);
+    DSC_TRACE_OP(ctx, "slice;get", x);
     DSC_ASSERT((unsigned) slices <= DSC_MAX_DIMS);
     if (slices > x->n_dim) DSC_LOG_FATAL("too many slices");
 
@@ -157,6 +159,7 @@ static void tensor_set(dsc_ctx *ctx, dsc_tensor *xa, const dsc_tensor *xb, int n
 extern "C" void dsc_tensor_set_idx(dsc_ctx *ctx, dsc_tensor *xa, const dsc_tensor *xb, int indexes, ...) {
     DSC_ASSERT(xa != nullptr);
     DSC_ASSERT(xb != nullptr);
+    DSC_TRACE_OP(ctx, "idx;set", xa, xb);
     DSC_ASSERT((unsigned) indexes <= (unsigned) xa->n_dim);
     DSC_ASSERT(xa->dtype == xb->dtype);
 
@@ -195,6 +198,7 @@ extern "C" void dsc_tensor_set_idx(dsc_ctx *ctx, dsc_tensor *xa, const dsc_tenso
 extern "C" void dsc_tensor_set_slice(dsc_ctx *ctx, dsc_tensor *xa, const dsc_tensor *xb, int slices, ...) {
     DSC_ASSERT(xa != nullptr);
     DSC_ASSERT(xb != nullptr);
+    DSC_TRACE_OP(ctx, "slice;set", xa, xb);
     DSC_ASSERT((unsigned) slices <= (unsigned) xa->n_dim);
     DSC_ASSERT(xa->dtype == xb->dtype);
 
@@ -224,6 +228,7 @@ extern "C" void dsc_tensor_set_slice(dsc_ctx *ctx, dsc_tensor *xa, const dsc_ten
 // dsc.cpp:764-827
 extern "C" dsc_tensor *dsc_transpose(dsc_ctx *ctx, const dsc_tensor *x, int axes, ...) {
     DSC_ASSERT(x != nullptr);
+    DSC_TRACE_OP(ctx, "op;transpose", x);
     if (x->n_dim == 1) return dsc_view(ctx, x);
 
     int swap_axes[DSC_MAX_DIMS];

@@ -91,6 +91,15 @@ void   dsc_tensor_free(dsc_ctx *ctx, dsc_tensor *x);        /* dsc.h:150, dsc.cp
 size_t dsc_used_mem(dsc_ctx *ctx);                          /* dsc.h:155, dsc.cpp:310-312 */
 void   dsc_print_mem_usage(dsc_ctx *ctx);                   /* dsc.h:157, dsc.cpp:314-322 */
 
+/* dsc.h:159-168, dsc_tracing.h — operator tracing.  While recording, every operator call logs its
+ * host-side begin / end AND the span its kernels took on the context's HIP stream (a pair of events); dsc_dump_traces
+ * writes a Perfetto / chrome://tracing JSON array with the reference's fields ("name", "cat", "ph", "ts", "pid", "tid",
+ * "args") on two tracks: tid 0 = API calls ("B" / "E"), tid 1 = device execution ("X" with "dur").  Always compiled in
+ * (the reference needs DSC_ENABLE_TRACING); not recording costs one branch per call. */
+void dsc_traces_record(dsc_ctx *ctx, bool record);
+void dsc_dump_traces(dsc_ctx *ctx, const char *filename);
+void dsc_clear_traces(dsc_ctx *ctx);
+
 /* dsc.h:173-198, dsc.cpp:342-428.  buffer == NULL allocates; otherwise the new tensor
  * shares (and references) `buffer`. */
 dsc_tensor *dsc_new_tensor(dsc_ctx *ctx, int n_dim, const int *shape, dsc_dtype dtype, dsc_tensor_buffer *buffer);
