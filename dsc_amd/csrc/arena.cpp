@@ -20,25 +20,38 @@ void dsc_main_arena::clear() {
     used_ = 0;
 }
 
-char *dsc_main_arena::alloc(size_t nb) {
+// from_top: carve the block from the END of the highest free block that fits.  Used for the long-lived FFT plan
+// tables: placed by best fit they end up wherever a tensor happened to be freed and cut the space for large tensors in
+// two (a [2048, 262144] f64 batch needs three contiguous 4 GiB blocks); kept at the top they stay out of the way.
+char *dsc_main_arena::alloc(size_t nb, bool from_top) {
     DSC_ASSERT(nb > 0);
     const size_t need = DSC_ALIGN_UP(nb, DSC_DEVICE_ALIGN);
 
     auto best = free_.end();
+    size_t largest = 0;
     for (auto it = free_.begin(); it != free_.end(); ++it) {
-        if (it->second >= need && (best == free_.end() || it->second < best->second)) best = it;
+        if (it->second > largest) largest = it->second;
+        if (it->second < need) continue;
+        if (from_top) best = it;                                            // address ordered: the last fitting block
+        else if (best == free_.end() || it->second < best->second) best = it;
     }
     if (best == free_.end()) {
-        DSC_LOG_FATAL("error allocating %.2fKB in the main HBM arena (%.1f of %.1f MB in use)",
-                      (double) need / 1024., (double) used_ / 1048576., (double) size_ / 1048576.);
+        DSC_LOG_FATAL("error allocating %.2fKB in the main HBM arena (%.1f of %.1f MB in use, largest free block %.1f MB)",
+                      (double) need / 1024., (double) used_ / 1048576., (double) size_ / 1048576., (double) largest / 1048576.);
     }
     const size_t off = best->first;
     const size_t left = best->second - need;
     free_.erase(best);
-    if (left > 0) free_[off + need] = left;
-    live_[off] = need;
+    size_t at = off;
+    if (from_top) {
+        at = off + left;
+        if (left > 0) free_[off] = left;
+    } else if (left > 0) {
+        free_[off + need] = left;
+    }
+    live_[at] = need;
     used_ += need;
-    return base_ + off;
+    return base_ + at;
 }
 
 void dsc_main_arena::free(char *p) {

@@ -75,7 +75,7 @@ static inline int dsc_pow2_n(int n) {
 class dsc_main_arena {
 public:
     void init(char *base, size_t size);
-    char *alloc(size_t nb);              // fatal when no block fits (dsc_allocator.cpp:112-114)
+    char *alloc(size_t nb, bool from_top = false);   // fatal when no block fits (dsc_allocator.cpp:112-114)
     void free(char *p);                  // unknown / already freed pointers are ignored (:152-181)
     void clear();
     size_t used() const { return used_; }

@@ -115,7 +115,7 @@ extern "C" dsc_fft_plan *dsc_plan_fft(dsc_ctx *ctx, int n, dsc_fft_type fft_type
     plan->last_used = 0;
     plan->dtype = twd;
     plan->fft_type = fft_type;
-    plan->block = ctx->main.alloc(total);
+    plan->block = ctx->main.alloc(total, true);          // long lived: from the top of the arena
     plan->tw_full = plan->block;
     plan->tw_real = real_bytes ? plan->block + full_bytes : nullptr;
     plan->tw_aux = aux_bytes ? plan->block + full_bytes + real_bytes : nullptr;
@@ -252,8 +252,9 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
 
     // register-resident 65536-point real transforms: contiguous full rows only
     if (sp && packed && j.L == 32768 && inner == 1 && plan->tw_aux != nullptr) {
-        if (j.mode == DSC_MODE_R2C_PACKED && j.in_len == 65536 && j.x->shape[j.slot] == 65536) {
-            dsc_launch_rfft64k((const float *) j.x->data, j.out->data, (int) n_lines, plan->tw_aux, ctx->n_cu, ctx->stream);
+        if (j.mode == DSC_MODE_R2C_PACKED) {               // any row length: shorter rows are zero padded, longer ones cropped
+            dsc_launch_rfft64k((const float *) j.x->data, j.out->data, (int) n_lines, j.x->shape[j.slot], j.in_len, plan->tw_aux, ctx->n_cu,
+                               ctx->stream);
             ctx->last_fft_path = "r2c_64k_regs";
             return;
         }
@@ -315,9 +316,11 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
     if (inner == 1 && !regs_mid_off && dsc_fft_regs_mid_supports(j.L, j.mode, sp)) {
         const int x_n = j.x->shape[j.slot];
         const int want = j.mode == DSC_MODE_R2C_PACKED ? 2 * j.L : j.mode == DSC_MODE_C2R_PACKED ? j.L + 1 : j.L;
-        if (j.in_len == want && x_n == want) {
+        const bool full = j.in_len == want && x_n == want;                    // else: zero padded or cropped lines
+        // byte pitch of a padded group must fit the kernel's 32-bit offsets
+        if (full || (long long) x_n * 16 * 64 < (1LL << 30)) {
             dsc_launch_fft_regs_mid(j.x->data, j.out->data, n_lines, j.L, j.mode, j.inverse, sp, plan->tw_full, plan->tw_real, j.scale,
-                                    ctx->stream);
+                                    full ? -1 : x_n, j.in_len, ctx->stream);
             ctx->last_fft_path = "regs_mid";
             return;
         }
@@ -445,13 +448,14 @@ extern "C" dsc_tensor *dsc_filter_fft(dsc_ctx *ctx, const dsc_tensor *s, const d
     DSC_ASSERT((n & (n - 1)) == 0);
 
     const int ls = s->shape[DSC_MAX_DIMS - 1];
-    if (s->dtype == DSC_F32 && H->dtype == DSC_C32 && n == 65536 && ls == 65536) {
+    if (s->dtype == DSC_F32 && H->dtype == DSC_C32 && n == 65536) {   // rows shorter than n are zero padded, longer ones cropped
         int out_shape[DSC_MAX_DIMS];
         memcpy(out_shape, s->shape, sizeof(out_shape));
         out_shape[DSC_MAX_DIMS - 1] = n;
         out = make_out(ctx, s, out, out_shape, DSC_F32);
         const dsc_fft_plan *plan = dsc_plan_fft(ctx, 32768, DSC_FFT_REAL, DSC_C32);
-        dsc_launch_filter64k((const float *) s->data, H->data, (float *) out->data, s->ne / ls, plan->tw_aux, ctx->n_cu, ctx->stream);
+        dsc_launch_filter64k((const float *) s->data, H->data, (float *) out->data, s->ne / ls, ls, ls < n ? ls : n, plan->tw_aux, ctx->n_cu,
+                             ctx->stream);
         ctx->last_fft_path = "filter_64k_regs";
         return out;
     }

@@ -298,8 +298,10 @@ __device__ __forceinline__ int partner_byte_addr(int wave, int lane) {
 
 // ------------------------------------------------------------------------------------------
 // forward: x [batch][65536] f32  ->  X [batch][32769] c32
+// in_pitch: floats between input rows; in_len <= 65536: valid samples per row — the rest of the transform length reads
+// as zero (dsc_rfft's zero padding, dsc.cpp:2125-2133) through the range check of the row's buffer descriptor.
 __global__ __launch_bounds__(1024) void rfft64k_kernel(const float *__restrict__ x, f2 *__restrict__ X, int batch,
-                                                       const f2 *__restrict__ aux PROBE_ARGS) {
+                                                       const f2 *__restrict__ aux, int in_pitch, int in_len PROBE_ARGS) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *plane = lds;
     f2 *w1024 = (f2 *) (lds + kPlaneFloats);
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(1024) void rfft64k_kernel(const float *__restrict__
     {
         const int row0 = blockIdx.x;
         const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(
-            (void *) (x + (size_t) row0 * 65536), 0, row0 < batch ? 65536 * 4 * IO_ON : 0, 0x00020000);
+            (void *) (x + (size_t) row0 * in_pitch), 0, row0 < batch ? in_len * 4 * IO_ON : 0, 0x00020000);
         const int load_off = thread_id(wave_sgpr) * 8;
 #pragma unroll
         for (int j1 = 0; j1 < 32; ++j1) v[j1] = load_c(r0, load_off, j1 * 8192);
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(1024) void rfft64k_kernel(const float *__restrict__
         // The next row's descriptor has zero records past the end of the batch: loads return 0.
         const int next_row = row + gridDim.x;
         const __amdgpu_buffer_rsrc_t rnext = __builtin_amdgcn_make_buffer_rsrc(
-            (void *) (x + (size_t) next_row * 65536), 0, next_row < batch ? 65536 * 4 * IO_ON : 0, 0x00020000);
+            (void *) (x + (size_t) next_row * in_pitch), 0, next_row < batch ? in_len * 4 * IO_ON : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t rout =
             __builtin_amdgcn_make_buffer_rsrc((void *) (X + (size_t) row * (kM + 1)), 0, (kM + 1) * 8 * IO_ON, 0x00020000);
 
@@ -611,7 +613,8 @@ __global__ __launch_bounds__(1024) void irfft64k_kernel(const f2 *__restrict__ X
 // post-pass pairs (X[k], X[M-k]), times (H[k], H[M-k]) read from L2, inverse pre-pass on the
 // same pair in the same lane, inverse passes.  4 B/sample in, 4 B/sample out.
 __global__ __launch_bounds__(1024) void filter64k_kernel(const float *__restrict__ x, const f2 *__restrict__ H,
-                                                         float *__restrict__ y, int batch, const f2 *__restrict__ aux) {
+                                                         float *__restrict__ y, int batch, const f2 *__restrict__ aux, int in_pitch,
+                                                         int in_len) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *plane = lds;
     f2 *w1024 = (f2 *) (lds + kPlaneFloats);
@@ -626,7 +629,7 @@ __global__ __launch_bounds__(1024) void filter64k_kernel(const float *__restrict
     {
         const int row0 = blockIdx.x;
         const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(
-            (void *) (x + (size_t) row0 * 65536), 0, row0 < batch ? 65536 * 4 : 0, 0x00020000);
+            (void *) (x + (size_t) row0 * in_pitch), 0, row0 < batch ? in_len * 4 : 0, 0x00020000);
         const int load_off = thread_id(wave_sgpr) * 8;
 #pragma unroll
         for (int j1 = 0; j1 < 32; ++j1) v[j1] = load_c(r0, load_off, j1 * 8192);
@@ -634,7 +637,7 @@ __global__ __launch_bounds__(1024) void filter64k_kernel(const float *__restrict
     for (int row = blockIdx.x; row < batch; row += gridDim.x) {
         const int next_row = row + gridDim.x;
         const __amdgpu_buffer_rsrc_t rnext = __builtin_amdgcn_make_buffer_rsrc(
-            (void *) (x + (size_t) next_row * 65536), 0, next_row < batch ? 65536 * 4 : 0, 0x00020000);
+            (void *) (x + (size_t) next_row * in_pitch), 0, next_row < batch ? in_len * 4 : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t rout =
             __builtin_amdgcn_make_buffer_rsrc((void *) (y + (size_t) row * 65536), 0, 65536 * 4, 0x00020000);
         three_passes<false>(v, plane, w1024, aux, wave_sgpr, false, true);     // v[p] = Z[c + 1024 br5(p)]
@@ -749,7 +752,7 @@ void dsc_r2c64k_build_tables(void *host_dst) {
     o[2 * (kAuxW1024 + 768)] = 0.f;  o[2 * (kAuxW1024 + 768) + 1] = 1.f;
 }
 
-void dsc_launch_rfft64k(const float *x, void *X, int batch, const void *aux, int n_cu, hipStream_t stream) {
+void dsc_launch_rfft64k(const float *x, void *X, int batch, int in_pitch, int in_len, const void *aux, int n_cu, hipStream_t stream) {
     if (batch <= 0) return;
     static bool attr_set = false;
     if (!attr_set) {
@@ -757,7 +760,7 @@ void dsc_launch_rfft64k(const float *x, void *X, int batch, const void *aux, int
         attr_set = true;
     }
     const int grid = batch < n_cu ? batch : n_cu;
-    hipLaunchKernelGGL(rfft64k_kernel, dim3(grid), dim3(1024), kLdsBytes, stream, x, (f2 *) X, batch, (const f2 *) aux PROBE_NULL);
+    hipLaunchKernelGGL(rfft64k_kernel, dim3(grid), dim3(1024), kLdsBytes, stream, x, (f2 *) X, batch, (const f2 *) aux, in_pitch, in_len PROBE_NULL);
 }
 
 void dsc_launch_irfft64k(const void *X, float *x, int batch, const void *aux, int n_cu, hipStream_t stream) {
@@ -770,7 +773,8 @@ void dsc_launch_irfft64k(const void *X, float *x, int batch, const void *aux, in
     const int grid = batch < n_cu ? batch : n_cu;
     hipLaunchKernelGGL(irfft64k_kernel, dim3(grid), dim3(1024), kLdsBytes, stream, (const f2 *) X, x, batch, (const f2 *) aux);
 }
-void dsc_launch_filter64k(const float *s, const void *H, float *y, int batch, const void *aux, int n_cu, hipStream_t stream) {
+void dsc_launch_filter64k(const float *s, const void *H, float *y, int batch, int in_pitch, int in_len, const void *aux, int n_cu,
+                          hipStream_t stream) {
     if (batch <= 0) return;
     static bool attr_set = false;
     if (!attr_set) {
@@ -778,5 +782,5 @@ void dsc_launch_filter64k(const float *s, const void *H, float *y, int batch, co
         attr_set = true;
     }
     const int grid = batch < n_cu ? batch : n_cu;
-    hipLaunchKernelGGL(filter64k_kernel, dim3(grid), dim3(1024), kLdsBytes, stream, s, (const f2 *) H, y, batch, (const f2 *) aux);
+    hipLaunchKernelGGL(filter64k_kernel, dim3(grid), dim3(1024), kLdsBytes, stream, s, (const f2 *) H, y, batch, (const f2 *) aux, in_pitch, in_len);
 }

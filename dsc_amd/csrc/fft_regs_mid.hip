@@ -57,10 +57,12 @@ template<typename R, int B, bool TWO>
 constexpr size_t mid_lds_bytes() { return ((size_t) mid_cfg<R, B, TWO>::PLANE + 2 * mid_cfg<R, B, TWO>::TABLE) * sizeof(R); }
 
 // MODE: DSC_MODE_C2C, DSC_MODE_R2C_CAST (L reals in), DSC_MODE_R2C_PACKED (forward only), DSC_MODE_C2R_PACKED (inverse only)
-template<typename R, int B, bool TWO, int MODE, bool INV>
+// PAD: input lines have a pitch of in_pitch_b bytes and in_len_b valid bytes; the rest of the transform length reads as zero
+// (zero padding / cropping of dsc_fft / dsc_rfft / dsc_irfft with n != axis length, dsc.cpp:1990-1998, 2125-2133, 2149-2157).
+template<typename R, int B, bool TWO, int MODE, bool INV, bool PAD>
 __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVES_PER_EU)) void fft_mid_kernel(
     const cpx<R> *__restrict__ in, cpx<R> *__restrict__ out, long long n_lines, const cpx<R> *__restrict__ tw_full,
-    const cpx<R> *__restrict__ tw_real, R scale) {
+    const cpx<R> *__restrict__ tw_real, R scale, int in_pitch_b, int in_len_b) {
     using C = cpx<R>;
     using cfg = mid_cfg<R, B, TWO>;
     constexpr int T = cfg::T, L = cfg::L, G = cfg::G, NT = cfg::NT, P1 = cfg::P1, P2 = cfg::P2, SP = cfg::SP, CPT = cfg::CPT;
@@ -87,10 +89,23 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
     constexpr bool kComplex = MODE == DSC_MODE_C2C || MODE == DSC_MODE_R2C_CAST;
     constexpr int LOADP = kComplex ? kStream : kCached;
     constexpr int STOREP = kComplex || (MODE == DSC_MODE_C2R_PACKED && !TWO) ? kStream : kCached;
-    const __amdgpu_buffer_rsrc_t rin =
-        __builtin_amdgcn_make_buffer_rsrc((void *) ((const char *) in + line0 * in_pitch * IB), 0, n_valid * in_pitch * IB, 0x00020000);
+    const int pitch_b = PAD ? in_pitch_b : in_pitch * IB;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+        (void *) ((const char *) in + line0 * pitch_b), 0, PAD ? (n_valid - 1) * pitch_b + in_len_b : n_valid * in_pitch * IB, 0x00020000);
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *) (out + line0 * out_pitch), 0, n_valid * out_pitch * CB, 0x00020000);
-    const int vin = (g * in_pitch + t) * IB;                       // byte offset of element t of this thread's line
+    const int vin = g * pitch_b + t * IB;                          // byte offset of element t of this thread's line
+    // element `idx` of the line (units of IB bytes); with PAD, elements past the valid length read zero (their offset is
+    // pushed out of the descriptor's range) and a sample pair cut by an odd length keeps its real part only
+    auto load_elem = [&](int idx) -> C {
+        constexpr int kOut = 0x7f000000;
+        if constexpr (MODE == DSC_MODE_R2C_CAST) {
+            return buf_load_real<LOADP>(rin, (!PAD || (t + idx) * IB < in_len_b) ? vin : kOut, idx * IB, R{});
+        } else {
+            C val = buf_load<LOADP>(rin, (!PAD || (t + idx) * CB < in_len_b) ? vin : kOut, idx * CB, R{});
+            if (PAD && MODE == DSC_MODE_R2C_PACKED && (t + idx) * CB + CB > in_len_b) val.y = (R) 0;
+            return val;
+        }
+    };
     const int vout = (g * out_pitch + t) * CB;
     R *stage = plane + g * SP;
 
@@ -98,17 +113,14 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
 
     C v[32];
 #pragma unroll
-    for (int j1 = 0; j1 < 32; ++j1) {                                                        // z[T j1 + t]
-        if constexpr (MODE == DSC_MODE_R2C_CAST) v[j1] = buf_load_real<LOADP>(rin, vin, j1 * T * IB, R{});
-        else                                     v[j1] = buf_load<LOADP>(rin, vin, j1 * T * CB, R{});
-    }
+    for (int j1 = 0; j1 < 32; ++j1) v[j1] = load_elem(T * j1);                               // z[T j1 + t]
 
     if constexpr (MODE == DSC_MODE_C2R_PACKED) {
         // Z[k] = (a + conj b)/2 + wq (a - conj b), a = Y[k], b = Y[L-k], wq = (i/2) conj(W_2L^k), for the
         // thread's own k = T j1 + t; b comes through the staging plane, one component at a time.
         const C wbase = tw_real[t];
         C yl = C{(R) 0, (R) 0};
-        if (t == 0) { yl = buf_load<LOADP>(rin, vin, L * CB, R{}); v[0].y = (R) 0; yl.y = (R) 0; }   // dsc_fft.h:227-228: real parts only at k = 0
+        if (t == 0) { yl = load_elem(L); v[0].y = (R) 0; yl.y = (R) 0; }   // dsc_fft.h:227-228: real parts only at k = 0
         R dx[32];
         R *up = stage + t;                          // up[T j1]         = stage[k]
         const R *dn = stage + (L - 31 * T) - t;     // dn[T (31 - j1)]  = stage[L - k]
@@ -263,29 +275,38 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
     }
 }
 
-template<typename R, int B, bool TWO, int MODE, bool INV>
-void launch_one(const void *in, void *out, long long n_lines, const void *tw_full, const void *tw_real, double scale, hipStream_t stream) {
+template<typename R, int B, bool TWO, int MODE, bool INV, bool PAD>
+void launch_pad(const void *in, void *out, long long n_lines, const void *tw_full, const void *tw_real, double scale, int in_pitch_b,
+                int in_len_b, hipStream_t stream) {
     using cfg = mid_cfg<R, B, TWO>;
     constexpr size_t lds = mid_lds_bytes<R, B, TWO>();
     static bool attr_set = false;
     if (!attr_set) {
-        (void) hipFuncSetAttribute((const void *) fft_mid_kernel<R, B, TWO, MODE, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        (void) hipFuncSetAttribute((const void *) fft_mid_kernel<R, B, TWO, MODE, INV, PAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         attr_set = true;
     }
     const long long groups = (n_lines + cfg::G - 1) / cfg::G;
-    hipLaunchKernelGGL((fft_mid_kernel<R, B, TWO, MODE, INV>), dim3((unsigned) groups), dim3(cfg::NT), lds, stream, (const cpx<R> *) in,
-                       (cpx<R> *) out, n_lines, (const cpx<R> *) tw_full, (const cpx<R> *) tw_real, (R) scale);
+    hipLaunchKernelGGL((fft_mid_kernel<R, B, TWO, MODE, INV, PAD>), dim3((unsigned) groups), dim3(cfg::NT), lds, stream, (const cpx<R> *) in,
+                       (cpx<R> *) out, n_lines, (const cpx<R> *) tw_full, (const cpx<R> *) tw_real, (R) scale, in_pitch_b, in_len_b);
+}
+
+// in_pitch_b < 0: full contiguous lines (the fast instantiation)
+template<typename R, int B, bool TWO, int MODE, bool INV>
+void launch_one(const void *in, void *out, long long n_lines, const void *tw_full, const void *tw_real, double scale, int in_pitch_b,
+                int in_len_b, hipStream_t stream) {
+    if (in_pitch_b < 0) launch_pad<R, B, TWO, MODE, INV, false>(in, out, n_lines, tw_full, tw_real, scale, 0, 0, stream);
+    else                launch_pad<R, B, TWO, MODE, INV, true>(in, out, n_lines, tw_full, tw_real, scale, in_pitch_b, in_len_b, stream);
 }
 
 template<typename R, int B, bool TWO>
 void launch_b(const void *in, void *out, long long n_lines, dsc_fft_mode mode, bool inverse, const void *tw_full, const void *tw_real,
-              double scale, hipStream_t stream) {
-    if (mode == DSC_MODE_R2C_PACKED)      launch_one<R, B, TWO, DSC_MODE_R2C_PACKED, false>(in, out, n_lines, tw_full, tw_real, scale, stream);
-    else if (mode == DSC_MODE_C2R_PACKED) launch_one<R, B, TWO, DSC_MODE_C2R_PACKED, true>(in, out, n_lines, tw_full, tw_real, scale, stream);
-    else if (mode == DSC_MODE_R2C_CAST && !inverse) launch_one<R, B, TWO, DSC_MODE_R2C_CAST, false>(in, out, n_lines, tw_full, tw_real, scale, stream);
-    else if (mode == DSC_MODE_R2C_CAST)   launch_one<R, B, TWO, DSC_MODE_R2C_CAST, true>(in, out, n_lines, tw_full, tw_real, scale, stream);
-    else if (inverse)                     launch_one<R, B, TWO, DSC_MODE_C2C, true>(in, out, n_lines, tw_full, tw_real, scale, stream);
-    else                                  launch_one<R, B, TWO, DSC_MODE_C2C, false>(in, out, n_lines, tw_full, tw_real, scale, stream);
+              double scale, int pb, int lb, hipStream_t stream) {
+    if (mode == DSC_MODE_R2C_PACKED)      launch_one<R, B, TWO, DSC_MODE_R2C_PACKED, false>(in, out, n_lines, tw_full, tw_real, scale, pb, lb, stream);
+    else if (mode == DSC_MODE_C2R_PACKED) launch_one<R, B, TWO, DSC_MODE_C2R_PACKED, true>(in, out, n_lines, tw_full, tw_real, scale, pb, lb, stream);
+    else if (mode == DSC_MODE_R2C_CAST && !inverse) launch_one<R, B, TWO, DSC_MODE_R2C_CAST, false>(in, out, n_lines, tw_full, tw_real, scale, pb, lb, stream);
+    else if (mode == DSC_MODE_R2C_CAST)   launch_one<R, B, TWO, DSC_MODE_R2C_CAST, true>(in, out, n_lines, tw_full, tw_real, scale, pb, lb, stream);
+    else if (inverse)                     launch_one<R, B, TWO, DSC_MODE_C2C, true>(in, out, n_lines, tw_full, tw_real, scale, pb, lb, stream);
+    else                                  launch_one<R, B, TWO, DSC_MODE_C2C, false>(in, out, n_lines, tw_full, tw_real, scale, pb, lb, stream);
 }
 
 }  // namespace
@@ -297,27 +318,32 @@ bool dsc_fft_regs_mid_supports(int L, dsc_fft_mode mode, bool single_precision) 
 
 template<typename R>
 static void launch_len(const void *in, void *out, long long n_lines, int L, dsc_fft_mode mode, bool inverse, const void *tw_full,
-                       const void *tw_real, double scale, hipStream_t stream) {
+                       const void *tw_real, double scale, int pb, int lb, hipStream_t stream) {
     switch (L) {
-        case 256:   launch_b<R, 8, true>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
-        case 512:   launch_b<R, 16, true>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
-        case 1024:  launch_b<R, 32, true>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
-        case 2048:  launch_b<R, 2, false>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
-        case 4096:  launch_b<R, 4, false>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
-        case 8192:  launch_b<R, 8, false>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
-        default:    launch_b<R, 16, false>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream); break;
+        case 256:   launch_b<R, 8, true>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, pb, lb, stream); break;
+        case 512:   launch_b<R, 16, true>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, pb, lb, stream); break;
+        case 1024:  launch_b<R, 32, true>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, pb, lb, stream); break;
+        case 2048:  launch_b<R, 2, false>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, pb, lb, stream); break;
+        case 4096:  launch_b<R, 4, false>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, pb, lb, stream); break;
+        case 8192:  launch_b<R, 8, false>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, pb, lb, stream); break;
+        default:    launch_b<R, 16, false>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, pb, lb, stream); break;
     }
 }
 
+// in_pitch / in_len: input line pitch and valid length in INPUT ELEMENTS (reals for R2C_PACKED / R2C_CAST, complex otherwise);
+// in_pitch < 0 = full contiguous lines.
 void dsc_launch_fft_regs_mid(const void *in, void *out, long long n_lines, int L, dsc_fft_mode mode, bool inverse, bool single_precision,
-                             const void *tw_full, const void *tw_real, double scale, hipStream_t stream) {
+                             const void *tw_full, const void *tw_real, double scale, long long in_pitch, int in_len, hipStream_t stream) {
     if (n_lines <= 0) return;
+    const int real_b = single_precision ? 4 : 8;
+    const int elem_b = (mode == DSC_MODE_R2C_PACKED || mode == DSC_MODE_R2C_CAST) ? real_b : 2 * real_b;
+    const int pb = in_pitch < 0 ? -1 : (int) (in_pitch * elem_b), lb = in_pitch < 0 ? 0 : in_len * elem_b;
     if (!single_precision) {
-        launch_len<double>(in, out, n_lines, L, mode, inverse, tw_full, tw_real, scale, stream);
+        launch_len<double>(in, out, n_lines, L, mode, inverse, tw_full, tw_real, scale, pb, lb, stream);
     } else if (L == 32768) {
-        if (inverse) launch_one<float, 32, false, DSC_MODE_C2C, true>(in, out, n_lines, tw_full, tw_real, scale, stream);
-        else         launch_one<float, 32, false, DSC_MODE_C2C, false>(in, out, n_lines, tw_full, tw_real, scale, stream);
+        if (inverse) launch_one<float, 32, false, DSC_MODE_C2C, true>(in, out, n_lines, tw_full, tw_real, scale, pb, lb, stream);
+        else         launch_one<float, 32, false, DSC_MODE_C2C, false>(in, out, n_lines, tw_full, tw_real, scale, pb, lb, stream);
     } else {
-        launch_len<float>(in, out, n_lines, L, mode, inverse, tw_full, tw_real, scale, stream);
+        launch_len<float>(in, out, n_lines, L, mode, inverse, tw_full, tw_real, scale, pb, lb, stream);
     }
 }

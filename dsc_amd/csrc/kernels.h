@@ -67,10 +67,12 @@ void dsc_launch_fft_unpack(const void *work, void *out, long long q_first, long 
 // aux: tables built by dsc_r2c64k_build_tables (device pointer).
 size_t dsc_r2c64k_table_bytes();
 void   dsc_r2c64k_build_tables(void *host_dst);          // fills a host staging buffer of table_bytes
-void   dsc_launch_rfft64k(const float *x, void *X, int batch, const void *aux, int n_cu, hipStream_t stream);
+// in_pitch: floats between input rows; in_len <= 65536 valid samples per row, the rest reads as zero (zero padding / crop)
+void   dsc_launch_rfft64k(const float *x, void *X, int batch, int in_pitch, int in_len, const void *aux, int n_cu, hipStream_t stream);
 void   dsc_launch_irfft64k(const void *X, float *x, int batch, const void *aux, int n_cu, hipStream_t stream);
 // y = irfft(rfft(s) * H) fused; H: [32769] c32
-void   dsc_launch_filter64k(const float *s, const void *H, float *y, int batch, const void *aux, int n_cu, hipStream_t stream);
+void   dsc_launch_filter64k(const float *s, const void *H, float *y, int batch, int in_pitch, int in_len, const void *aux, int n_cu,
+                            hipStream_t stream);
 
 // ---- 262144-point real transforms in f64 (config 5): radix-8 pass + register-resident 16384-point
 // c64 FFTs + post-pass (fft_r2c_256k_f64.hip).  x: [rows][262144] f64, X: [rows][131073] c64,
@@ -93,8 +95,10 @@ void   dsc_launch_rfft_two_pass(const void *in, void *out, long long rows, int L
 // (fft_regs_mid.hip).  in / out: [n_lines][L] complex (C2C), [n_lines][2L] reals -> [n_lines][L+1] bins
 // (R2C_PACKED) or the converse (C2R_PACKED).  tw_full: W_L^k, k < L; tw_real: W_{2L}^k, k <= L.
 bool dsc_fft_regs_mid_supports(int L, dsc_fft_mode mode, bool single_precision);
+// in_pitch / in_len: input line pitch and valid length in input elements (reals for R2C_PACKED / R2C_CAST, complex otherwise):
+// shorter lines are zero padded, longer ones cropped; in_pitch < 0 = full contiguous lines (the fast instantiation).
 void dsc_launch_fft_regs_mid(const void *in, void *out, long long n_lines, int L, dsc_fft_mode mode, bool inverse, bool single_precision,
-                             const void *tw_full, const void *tw_real, double scale, hipStream_t stream);
+                             const void *tw_full, const void *tw_real, double scale, long long in_pitch, int in_len, hipStream_t stream);
 
 // ---- element-wise ------------------------------------------------------------------------
 // dtype codes are dsc_dtype values (0 f32, 1 f64, 2 c32, 3 c64)

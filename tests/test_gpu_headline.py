@@ -32,8 +32,11 @@ def test_paths_are_the_hand_written_kernels(dsc):
     H = dsc.from_numpy(np.ones(N // 2 + 1, np.complex64))
     dsc.filter_fft(x, H)
     assert dsc.last_fft_path() == 'filter_64k_regs'
+    # zero-padded / cropped rows stay on the register kernel (the row's buffer descriptor ends at the last valid sample)
+    dsc.rfft(dsc.from_numpy(np.ones((2, 60000), np.float32)))
+    assert dsc.last_fft_path() == 'r2c_64k_regs'
     # anything the fast kernels do not cover must still be right through the generic path
-    dsc.rfft(dsc.from_numpy(np.ones((2, 60000), np.float32)))          # zero-padded rows
+    dsc.rfft(dsc.from_numpy(np.ones((65536, 2), np.float32)), axis=0)
     assert dsc.last_fft_path() == 'generic_4step'
 
 
@@ -363,3 +366,63 @@ def test_two_pass_long_transforms(dsc, dt, n):
         bh = back.numpy()
         assert_close(bh[0], port.irfft(Xq[0]), what=f'irfft {np.dtype(dt).name} n={n}')
         assert rel_l2(bh, x) <= exact
+
+
+@pytest.mark.parametrize('ls', [60001, 65000, 32769, 1, 70000])
+def test_padded_and_cropped_rows_on_the_register_kernels(dsc, ls):
+    """dsc_rfft(x, n) with rows shorter (zero padding, dsc.cpp:2125-2133; odd lengths split a sample pair) or longer
+    (crop) than the transform, and the README pipeline on such rows (README.md:113-135: s is padded to the transform
+    length inside rfft), against the oracle."""
+    from oracle import port
+    rng = np.random.default_rng(ls)
+    rows = 5
+    x = rng.standard_normal((rows, ls)).astype(np.float32)
+    X = dsc.rfft(dsc.from_numpy(x), n=N)
+    assert dsc.last_fft_path() == 'r2c_64k_regs'
+    got = X.numpy()
+    for r in (0, rows - 1):
+        assert_close(got[r], port.rfft(x[r], N), what=f'padded rfft ls={ls} row {r}')
+    xp = np.zeros((rows, N), np.float32)
+    xp[:, :min(ls, N)] = x[:, :N]
+    assert rel_l2(got, np.fft.rfft(xp.astype(np.float64), axis=-1)) <= 1e-6
+    taps = np.zeros(N, np.float32)
+    taps[:97] = rng.standard_normal(97).astype(np.float32)
+    H = port.rfft(taps)
+    y = dsc.filter_fft(dsc.from_numpy(x), dsc.from_numpy(H))
+    assert dsc.last_fft_path() == 'filter_64k_regs' and y.shape == (rows, N)
+    want = port.irfft(port.mul(port.rfft(x[1], N), H))
+    assert_close(y.numpy()[1], want, what=f'padded filter ls={ls}')
+
+
+@pytest.mark.parametrize('dt', [np.float32, np.float64])
+@pytest.mark.parametrize('n', [1024, 8192, 32768])
+def test_mid_sizes_padded_and_cropped(dsc, dt, n):
+    """Zero padding / cropping on the register kernels of fft_regs_mid.hip: every transform (rfft, irfft, fft, ifft, fft of
+    real input) with axis lengths below (odd ones cut a sample pair) and above the transform length, rows that do not fill
+    the last workgroup, against the oracle."""
+    from oracle import port
+    cdt = np.complex64 if dt == np.float32 else np.complex128
+    rng = np.random.default_rng(n)
+    tol = 1e-6 if dt == np.float32 else 1e-14
+    for rows, ls in ((3, n - 1), (11, n // 2 + 7), (5, n + 100), (2, 1)):
+        x = rng.standard_normal((rows, ls)).astype(dt)
+        got = dsc.rfft(dsc.from_numpy(x), n=n)
+        assert dsc.last_fft_path() == 'regs_mid', (n, ls)
+        assert_close(got.numpy()[rows - 1], port.rfft(x[rows - 1], n), what=f'rfft n={n} ls={ls}')
+        xp = np.zeros((rows, n), dt)
+        xp[:, :min(ls, n)] = x[:, :n]
+        assert rel_l2(got.numpy(), np.fft.rfft(xp.astype(np.float64), axis=-1)) <= tol
+        c = (rng.standard_normal((rows, ls)) + 1j * rng.standard_normal((rows, ls))).astype(cdt)
+        for name in ('fft', 'ifft'):
+            g = getattr(dsc, name)(dsc.from_numpy(c), n=n // 2)
+            assert dsc.last_fft_path() == ('regs_mid' if n // 2 >= 256 else 'generic_lds')
+            assert_close(g.numpy()[0], getattr(port, name)(c[0], n // 2), what=f'{name} n={n // 2} ls={ls}')
+        g = dsc.fft(dsc.from_numpy(x), n=n // 2)              # real input, cast on load
+        assert_close(g.numpy()[rows - 1], port.fft(x[rows - 1], n // 2), what=f'fft(real) n={n // 2} ls={ls}')
+        # irfft: `n` counts bins (dsc.cpp:2199-2200); fewer bins than n/2+1 are zero filled, more are cropped
+        bins = n // 2 + 1
+        Y = (rng.standard_normal((rows, ls)) + 1j * rng.standard_normal((rows, ls))).astype(cdt)
+        if ls >= 2:
+            b = dsc.irfft(dsc.from_numpy(Y), n=bins)
+            assert dsc.last_fft_path() == 'regs_mid'
+            assert_close(b.numpy()[0], port.irfft(Y[0], bins), what=f'irfft bins={bins} ls={ls}')

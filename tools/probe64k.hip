@@ -31,10 +31,10 @@ int main(int argc, char **argv) {
     CK(hipEventCreate(&e1));
     for (int io_on = 1; io_on >= 0; --io_on) {
         for (int rep = 0; rep < 60; ++rep)                                   // clock ramp
-            hipLaunchKernelGGL(rfft64k_kernel, dim3(256), dim3(1024), kLdsBytes, 0, x, X, batch, aux, io_on);
+            hipLaunchKernelGGL(rfft64k_kernel, dim3(256), dim3(1024), kLdsBytes, 0, x, X, batch, aux, 65536, 65536, io_on);
         CK(hipEventRecord(e0));
         for (int rep = 0; rep < 20; ++rep)
-            hipLaunchKernelGGL(rfft64k_kernel, dim3(256), dim3(1024), kLdsBytes, 0, x, X, batch, aux, io_on);
+            hipLaunchKernelGGL(rfft64k_kernel, dim3(256), dim3(1024), kLdsBytes, 0, x, X, batch, aux, 65536, 65536, io_on);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms;
