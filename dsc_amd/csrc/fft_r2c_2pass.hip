@@ -60,7 +60,8 @@ __device__ __forceinline__ void four_step_twiddle(cpx<R> (&v)[32], const cpx<R> 
 //   "reader" lanes  tid = 32 q + tau: line j1 = 16 a + q, holds index tau + 32 k3 (pieces of 32 elements across tau)
 template<typename R, int B1, bool INV>
 __global__ __launch_bounds__(512, (waves_per_eu<R>())) void two_pass_rows_kernel(const cpx<R> *__restrict__ in, cpx<R> *__restrict__ out,
-                                                                              const cpx<R> *__restrict__ twL, R scale) {
+                                                                              const cpx<R> *__restrict__ twL, R scale, long long ext_pitch_b,
+                                                                              int ext_len_b) {
     using C = cpx<R>;
     constexpr int L1 = 32 * B1, L = L1 * 1024, CB = (int) sizeof(C), GROUPS = L1 / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -70,8 +71,12 @@ __global__ __launch_bounds__(512, (waves_per_eu<R>())) void two_pass_rows_kernel
     for (int i = tid; i < 1024; i += 512) w1024[i] = twL[i * L1];            // W_1024^m = W_L^{L1 m}
     const long long row = blockIdx.x / GROUPS;
     const int a = blockIdx.x % GROUPS;
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *) (in + row * L), 0, L * CB, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *) (out + row * L), 0, L * CB, 0x00020000);
+    // The external side (forward: the input samples; inverse: the output samples) has a row pitch of ext_pitch_b bytes and
+    // ext_len_b valid bytes: shorter rows are zero padded by the descriptor's range check (dsc.cpp:2125-2133).
+    const __amdgpu_buffer_rsrc_t rin = INV ? __builtin_amdgcn_make_buffer_rsrc((void *) (in + row * L), 0, L * CB, 0x00020000)
+                                           : __builtin_amdgcn_make_buffer_rsrc((void *) ((const char *) in + row * ext_pitch_b), 0, ext_len_b, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = INV ? __builtin_amdgcn_make_buffer_rsrc((void *) ((char *) out + row * ext_pitch_b), 0, ext_len_b, 0x00020000)
+                                            : __builtin_amdgcn_make_buffer_rsrc((void *) (out + row * L), 0, L * CB, 0x00020000);
     const int wq = tid & 15, wt = tid >> 4;              // writer mapping
     const int rq = tid >> 5, rtau = tid & 31;            // reader mapping
     const int zoff = ((16 * a + wq) + L1 * wt) * CB;     // z[j1 + L1 (32 j2' + t)]: + j2' * 32 L1 elements
@@ -162,7 +167,8 @@ struct stage_ptrs {
 //   element e = B1 i' + p of a thread after the transform: k1 = t + B1 i' + 32 k3, k3 = brev(p)
 template<typename R, int B1, bool INV>
 __global__ __launch_bounds__(512, (waves_per_eu<R>())) void two_pass_cols_kernel(const cpx<R> *__restrict__ in, cpx<R> *__restrict__ out,
-                                                                              const cpx<R> *__restrict__ twL, const cpx<R> *__restrict__ tw_real) {
+                                                                              const cpx<R> *__restrict__ twL, const cpx<R> *__restrict__ tw_real,
+                                                                              long long bins_pitch, int bins_len) {
     using C = cpx<R>;
     constexpr int L1 = 32 * B1, L = L1 * 1024, CB = (int) sizeof(C);
     constexpr int NC = 512 / B1, H = NC / 2, BLOCKS = 1024 / NC, CPT = 32 / B1, LOGB = ilog2(B1);
@@ -181,9 +187,10 @@ __global__ __launch_bounds__(512, (waves_per_eu<R>())) void two_pass_cols_kernel
     const int col = col0 ? 0 : ell < H ? H * b + 1 + ell : 1024 - H - H * b + (ell - H);
     const int ellp = (last && (ell == H - 1 || ell == H)) ? ell : NC - 1 - ell;   // local column of the pairing partner
     const C *work = INV ? out + row * L : in + row * L;
-    const C *bins = INV ? in + row * (L + 1LL) : out + row * (L + 1LL);
+    // bins_pitch / bins_len (in bins): the inverse reads rows of any length, missing bins as zero (dsc.cpp:2149-2157)
+    const C *bins = INV ? in + row * bins_pitch : out + row * bins_pitch;
     const __amdgpu_buffer_rsrc_t rwork = __builtin_amdgcn_make_buffer_rsrc((void *) work, 0, L * CB, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rbins = __builtin_amdgcn_make_buffer_rsrc((void *) bins, 0, (L + 1) * CB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbins = __builtin_amdgcn_make_buffer_rsrc((void *) bins, 0, bins_len * CB, 0x00020000);
     const int woff = (t * 1024 + col) * CB;
     const int boff = col * CB;
 
@@ -322,9 +329,10 @@ __global__ __launch_bounds__(512, (waves_per_eu<R>())) void two_pass_cols_kernel
     }
 }
 
+// in_pitch / in_len: pitch and valid length of the INPUT rows in input elements (reals forward, bins inverse)
 template<typename R, int B1>
 void launch_pair(const void *in, void *out, long long rows, void *work, const void *tw_full, const void *tw_real, bool inverse,
-                 hipStream_t stream) {
+                 long long in_pitch, int in_len, hipStream_t stream) {
     using C = cpx<R>;
     constexpr int L = 32 * B1 * 1024;
     constexpr int rl = rows_lds_bytes<R>(), cl = cols_lds_bytes<R, B1>();
@@ -337,26 +345,28 @@ void launch_pair(const void *in, void *out, long long rows, void *work, const vo
         done = true;
     }
     const dim3 grid((unsigned) (rows * 2 * B1));          // L1 / 16 row groups = 1024 / NC column blocks = 2 B1 per transform
+    constexpr long long full_row_b = 2LL * L * sizeof(R);
     if (!inverse) {
-        hipLaunchKernelGGL((two_pass_rows_kernel<R, B1, false>), grid, dim3(512), rl, stream, (const C *) in, (C *) work, (const C *) tw_full, (R) 1);
+        hipLaunchKernelGGL((two_pass_rows_kernel<R, B1, false>), grid, dim3(512), rl, stream, (const C *) in, (C *) work, (const C *) tw_full, (R) 1,
+                           in_pitch * (long long) sizeof(R), (int) (in_len * sizeof(R)));
         hipLaunchKernelGGL((two_pass_cols_kernel<R, B1, false>), grid, dim3(512), cl, stream, (const C *) work, (C *) out, (const C *) tw_full,
-                           (const C *) tw_real);
+                           (const C *) tw_real, (long long) (L + 1), L + 1);
     } else {
         hipLaunchKernelGGL((two_pass_cols_kernel<R, B1, true>), grid, dim3(512), cl, stream, (const C *) in, (C *) work, (const C *) tw_full,
-                           (const C *) tw_real);
+                           (const C *) tw_real, in_pitch, in_len);
         hipLaunchKernelGGL((two_pass_rows_kernel<R, B1, true>), grid, dim3(512), rl, stream, (const C *) work, (C *) out, (const C *) tw_full,
-                           (R) (1.0 / (double) L));                                         // 2/(2n), dsc_fft.h:232
+                           (R) (1.0 / (double) L), full_row_b, (int) full_row_b);                 // 2/(2n), dsc_fft.h:232
     }
 }
 
 template<typename R>
 void launch_len(int L, const void *in, void *out, long long rows, void *work, const void *tw_full, const void *tw_real, bool inverse,
-                hipStream_t stream) {
+                long long in_pitch, int in_len, hipStream_t stream) {
     switch (L) {
-        case 32768:  launch_pair<R, 1>(in, out, rows, work, tw_full, tw_real, inverse, stream); break;
-        case 65536:  launch_pair<R, 2>(in, out, rows, work, tw_full, tw_real, inverse, stream); break;
-        case 131072: launch_pair<R, 4>(in, out, rows, work, tw_full, tw_real, inverse, stream); break;
-        default:     launch_pair<R, 8>(in, out, rows, work, tw_full, tw_real, inverse, stream); break;
+        case 32768:  launch_pair<R, 1>(in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream); break;
+        case 65536:  launch_pair<R, 2>(in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream); break;
+        case 131072: launch_pair<R, 4>(in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream); break;
+        default:     launch_pair<R, 8>(in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream); break;
     }
 }
 
@@ -367,11 +377,12 @@ bool dsc_fft_two_pass_supports(int L, bool single_precision) {
     return L == 65536 || L == 131072 || L == 262144;
 }
 
-// forward: in = [rows][2L] reals, out = [rows][L + 1] bins; inverse: the converse.  work: rows * L complex of scratch.
-// tw_full: W_L^k, k < L; tw_real: W_{2L}^k, k <= L (the REAL plan's own tables).
+// forward: in = [rows][in_pitch] reals of which in_len <= 2L are transformed (the rest of the length is zero), out =
+// [rows][L + 1] bins; inverse: in = [rows][in_pitch] bins of which in_len <= L + 1 are used, out = [rows][2L] reals.
+// work: rows * L complex of scratch.  tw_full: W_L^k, k < L; tw_real: W_{2L}^k, k <= L (the REAL plan's own tables).
 void dsc_launch_rfft_two_pass(const void *in, void *out, long long rows, int L, bool inverse, bool single_precision, void *work,
-                              const void *tw_full, const void *tw_real, hipStream_t stream) {
+                              const void *tw_full, const void *tw_real, long long in_pitch, int in_len, hipStream_t stream) {
     if (rows <= 0) return;
-    if (single_precision) launch_len<float>(L, in, out, rows, work, tw_full, tw_real, inverse, stream);
-    else                  launch_len<double>(L, in, out, rows, work, tw_full, tw_real, inverse, stream);
+    if (single_precision) launch_len<float>(L, in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream);
+    else                  launch_len<double>(L, in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream);
 }

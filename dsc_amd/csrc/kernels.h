@@ -85,11 +85,13 @@ void   dsc_launch_irfft256k_f64(const void *X, double *x, long long rows, void *
                                 int n_cu, hipStream_t stream);
 
 // ---- long real transforms in two passes over HBM (fft_r2c_2pass.hip): packed complex length L = 32768 (f64 only),
-// 65536, 131072, 262144; f32 and f64.  forward: in = [rows][2L] reals -> out = [rows][L + 1] bins; inverse: the converse.
+// 65536, 131072, 262144; f32 and f64.  forward: reals -> out = [rows][L + 1] bins; inverse: bins -> [rows][2L] reals.
 // work: rows * L complex of scratch; tw_full: W_L^k, k < L; tw_real: W_{2L}^k, k <= L (the REAL plan's own tables).
 bool   dsc_fft_two_pass_supports(int L, bool single_precision);
+// in_pitch / in_len: pitch and valid length of the input rows in input elements (reals forward, bins inverse): shorter rows are zero
+// padded, longer ones cropped.
 void   dsc_launch_rfft_two_pass(const void *in, void *out, long long rows, int L, bool inverse, bool single_precision, void *work,
-                                const void *tw_full, const void *tw_real, hipStream_t stream);
+                                const void *tw_full, const void *tw_real, long long in_pitch, int in_len, hipStream_t stream);
 
 // ---- register-resident transforms of contiguous full lines, complex length 256 .. 16384 (f32, f64; f32 C2C also 32768)
 // (fft_regs_mid.hip).  in / out: [n_lines][L] complex (C2C), [n_lines][2L] reals -> [n_lines][L+1] bins

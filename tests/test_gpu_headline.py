@@ -426,3 +426,22 @@ def test_mid_sizes_padded_and_cropped(dsc, dt, n):
             b = dsc.irfft(dsc.from_numpy(Y), n=bins)
             assert dsc.last_fft_path() == 'regs_mid'
             assert_close(b.numpy()[0], port.irfft(Y[0], bins), what=f'irfft bins={bins} ls={ls}')
+
+
+@pytest.mark.parametrize('dt,n', [(np.float32, 131072), (np.float64, 65536), (np.float64, 262144)])
+def test_two_pass_padded_rows(dsc, dt, n):
+    """Zero padded / cropped rows on the two-pass kernels (the row descriptors end at the last valid sample / bin)."""
+    from oracle import port
+    cdt = np.complex64 if dt == np.float32 else np.complex128
+    rng = np.random.default_rng(n + 5)
+    for rows, ls in ((3, n - 1), (2, n // 2 + 3), (2, n + 64)):
+        x = rng.standard_normal((rows, ls)).astype(dt)
+        got = dsc.rfft(dsc.from_numpy(x), n=n)
+        assert dsc.last_fft_path() == 'r2c_2pass_regs'
+        assert_close(got.numpy()[rows - 1], port.rfft(x[rows - 1], n), what=f'padded 2-pass rfft n={n} ls={ls}')
+    bins = n // 2 + 1
+    for rows, lb in ((2, bins - 5), (3, bins + 9)):
+        Y = (rng.standard_normal((rows, lb)) + 1j * rng.standard_normal((rows, lb))).astype(cdt)
+        b = dsc.irfft(dsc.from_numpy(Y), n=bins)
+        assert dsc.last_fft_path() == 'c2r_2pass_regs'
+        assert_close(b.numpy()[0], port.irfft(Y[0], bins), what=f'padded 2-pass irfft bins={bins} lb={lb}')
