@@ -269,16 +269,18 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
     // kernel with the real pass fused (fft_r2c_2pass.hip).  DSC_C5_3PASS=1 selects the first, three-pass version of the
     // f64 262144-point case for A/B.
     static const bool two_pass_off = getenv("DSC_NO_TWO_PASS") != nullptr;        // A/B aid (tools/bench_mid.py)
-    if (packed && inner == 1 && !two_pass_off && dsc_fft_two_pass_supports(j.L, sp)) {
+    if ((packed || j.mode == DSC_MODE_C2C) && inner == 1 && !two_pass_off && dsc_fft_two_pass_supports(j.L, sp)) {
         const int L = j.L;
-        const bool fwd = j.mode == DSC_MODE_R2C_PACKED, inv = !fwd;       // any row length: zero padded / cropped by the row descriptors
+        const bool cplx = !packed;                                        // dsc_fft / dsc_ifft of a complex tensor
+        const bool fwd = cplx ? !j.inverse : j.mode == DSC_MODE_R2C_PACKED, inv = !fwd;   // any row length: padded / cropped by the row descriptors
         const long long x_n = j.x->shape[j.slot];
         {
             static const bool three_pass_env = getenv("DSC_C5_3PASS") != nullptr;
-            const bool three_pass = three_pass_env && !sp && L == 131072 && plan->tw_aux != nullptr && x_n == (fwd ? 2 * L : L + 1);
+            const bool three_pass = three_pass_env && !cplx && !sp && L == 131072 && plan->tw_aux != nullptr && x_n == (fwd ? 2 * L : L + 1);
             const size_t csz = sp ? 8 : 16;
             const size_t row_bytes = (size_t) L * csz;
-            const size_t real_row = (size_t) (fwd ? x_n : 2 * L) * (csz / 2), bins_row = (size_t) (fwd ? L + 1 : x_n) * csz;
+            const size_t real_row = cplx ? (size_t) (fwd ? x_n : L) * csz : (size_t) (fwd ? x_n : 2 * L) * (csz / 2);       // time-domain side
+            const size_t bins_row = cplx ? (size_t) (fwd ? L : x_n) * csz : (size_t) (fwd ? L + 1 : x_n) * csz;               // frequency-domain side
             ctx->scratch.reset();
             long long chunk = (long long) ((ctx->scratch.capacity() - DSC_DEVICE_ALIGN) / row_bytes);
             if (chunk < 1) DSC_LOG_FATAL("scratch arena too small: a %d-point transform needs %.1f MB of scratch per row", 2 * L, row_bytes / 1048576.);
@@ -299,14 +301,16 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
                 const long long nl = n_lines - q < chunk ? n_lines - q : chunk;
                 const char *src = (const char *) j.x->data + (size_t) q * (fwd ? real_row : bins_row);
                 char *dst = (char *) j.out->data + (size_t) q * (fwd ? bins_row : real_row);
-                if (!three_pass)
+                if (cplx)
+                    dsc_launch_fft_two_pass(src, dst, nl, L, inv, sp, work, plan->tw_full, x_n, j.in_len, ctx->stream);
+                else if (!three_pass)
                     dsc_launch_rfft_two_pass(src, dst, nl, L, inv, sp, work, plan->tw_full, plan->tw_real, x_n, j.in_len, ctx->stream);
                 else if (fwd)
                     dsc_launch_rfft256k_f64((const double *) src, dst, nl, work, plan->tw_aux, plan->tw_real, ctx->n_cu, ctx->stream);
                 else
                     dsc_launch_irfft256k_f64(src, (double *) dst, nl, work, plan->tw_aux, plan->tw_real, ctx->n_cu, ctx->stream);
             }
-            ctx->last_fft_path = fwd ? "r2c_2pass_regs" : "c2r_2pass_regs";
+            ctx->last_fft_path = cplx ? "c2c_2pass_regs" : fwd ? "r2c_2pass_regs" : "c2r_2pass_regs";
             return;
         }
     }

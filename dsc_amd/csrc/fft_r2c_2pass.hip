@@ -165,7 +165,8 @@ struct stage_ptrs {
 // cols kernel.  Forward: work[j1][k2] -> X (L + 1 bins).  Inverse: Y (L + 1 bins) -> work[j1][k2].
 //   lanes tid = NC t + ell: local column ell (S side 0..H-1, mirror side H..NC-1), slice t of the L1-point axis (j1 = B1 i + t)
 //   element e = B1 i' + p of a thread after the transform: k1 = t + B1 i' + 32 k3, k3 = brev(p)
-template<typename R, int B1, bool INV>
+//   REAL = false: plain complex transform (dsc_fft / dsc_ifft): columns NC b + ell, no pairing, rows of L bins
+template<typename R, int B1, bool INV, bool REAL>
 __global__ __launch_bounds__(512, (waves_per_eu<R>())) void two_pass_cols_kernel(const cpx<R> *__restrict__ in, cpx<R> *__restrict__ out,
                                                                               const cpx<R> *__restrict__ twL, const cpx<R> *__restrict__ tw_real,
                                                                               long long bins_pitch, int bins_len) {
@@ -183,8 +184,8 @@ __global__ __launch_bounds__(512, (waves_per_eu<R>())) void two_pass_cols_kernel
     const int b = blockIdx.x % BLOCKS;
     const int ell = tid % NC, t = tid / NC;
     const bool last = b == BLOCKS - 1;
-    const bool col0 = last && ell == H;                                       // column 0 replaces the duplicate 512
-    const int col = col0 ? 0 : ell < H ? H * b + 1 + ell : 1024 - H - H * b + (ell - H);
+    const bool col0 = REAL && last && ell == H;                               // column 0 replaces the duplicate 512
+    const int col = !REAL ? NC * b + ell : col0 ? 0 : ell < H ? H * b + 1 + ell : 1024 - H - H * b + (ell - H);
     const int ellp = (last && (ell == H - 1 || ell == H)) ? ell : NC - 1 - ell;   // local column of the pairing partner
     const C *work = INV ? out + row * L : in + row * L;
     // bins_pitch / bins_len (in bins): the inverse reads rows of any length, missing bins as zero (dsc.cpp:2149-2157)
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(512, (waves_per_eu<R>())) void two_pass_cols_kernel
 
     // W_2L^k for this thread's bins k = 1024 k1 + col, k1 = t + B1 i' + 32 k3: W_2L^{col} W_2L1^{t} times the constant
     // W_64^{i' + (32 / B1) k3}
-    const C wt0 = cmul(tw_real[col], tw_real[1024 * t]);
+    const C wt0 = REAL ? cmul(tw_real[col], tw_real[1024 * t]) : C{(R) 1, (R) 0};
     const stage_ptrs<R, B1> sp(plane, t, ell, ellp, col0);
 
     C u[32], v[32];
@@ -233,6 +234,11 @@ __global__ __launch_bounds__(512, (waves_per_eu<R>())) void two_pass_cols_kernel
             for (int k = 0; k < 32; ++k) v[k] = u[brev(k, 5)];                // one thread per column: v[k1]
         }
 
+        if constexpr (!REAL) {
+#pragma unroll
+            for (int e = 0; e < 32; ++e) buf_store<kStream>(v[e], rbins, boff, (t + B1 * (e / B1) + 32 * brev(e % B1, LOGB)) * BSTEP);
+            return;
+        }
         // ---- packed-real pass: a = Z[k1][col] (own), b = Z[L1 - 1 - k1][1024 - col] (L1 - k1 in column 0), through the plane
         R bx[32];
 #pragma unroll
@@ -269,6 +275,7 @@ __global__ __launch_bounds__(512, (waves_per_eu<R>())) void two_pass_cols_kernel
         C ylast = C{(R) 0, (R) 0};
         if (col0 && t == 0) { ylast = buf_load<kStream>(rbins, L * CB, 0, R{}); v[0].y = (R) 0; }      // real parts only at k = 0 and k = L
         __syncthreads();
+        if constexpr (REAL) {
         R bx[32];
 #pragma unroll
         for (int e = 0; e < 32; ++e) sp.mine(B1 * (e / B1) + 32 * (e % B1)) = v[e].x;
@@ -293,8 +300,9 @@ __global__ __launch_bounds__(512, (waves_per_eu<R>())) void two_pass_cols_kernel
             const R sx = ax + bx[e], sy = ay - by, dx = ax - bx[e], dy = ay + by;
             v[e] = C{(R) 0.5 * sx + (dx * wqx - dy * wqy), (R) 0.5 * sy + (dx * wqy + dy * wqx)};
         }
+        }
         if constexpr (B1 > 1) {
-            lds_barrier();
+            if constexpr (REAL) lds_barrier();
             // ---- inverse L1-point transform over k1 = k' + 32 k3: B1-point over k3 -> t', twiddle, exchange, 32-point over k'
             dft_columns<R, true, B1>(v, std::make_integer_sequence<int, CPT>{});      // v[B1 i' + p]: t' = brev(p)
 #pragma unroll
@@ -329,8 +337,9 @@ __global__ __launch_bounds__(512, (waves_per_eu<R>())) void two_pass_cols_kernel
     }
 }
 
-// in_pitch / in_len: pitch and valid length of the INPUT rows in input elements (reals forward, bins inverse)
-template<typename R, int B1>
+// in_pitch / in_len: pitch and valid length of the INPUT rows in input elements (REAL: reals forward, bins inverse; complex
+// transforms: complex samples both ways)
+template<typename R, int B1, bool REAL>
 void launch_pair(const void *in, void *out, long long rows, void *work, const void *tw_full, const void *tw_real, bool inverse,
                  long long in_pitch, int in_len, hipStream_t stream) {
     using C = cpx<R>;
@@ -340,33 +349,35 @@ void launch_pair(const void *in, void *out, long long rows, void *work, const vo
     if (!done) {
         (void) hipFuncSetAttribute((const void *) two_pass_rows_kernel<R, B1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, rl);
         (void) hipFuncSetAttribute((const void *) two_pass_rows_kernel<R, B1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, rl);
-        (void) hipFuncSetAttribute((const void *) two_pass_cols_kernel<R, B1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cl);
-        (void) hipFuncSetAttribute((const void *) two_pass_cols_kernel<R, B1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cl);
+        (void) hipFuncSetAttribute((const void *) two_pass_cols_kernel<R, B1, false, REAL>, hipFuncAttributeMaxDynamicSharedMemorySize, cl);
+        (void) hipFuncSetAttribute((const void *) two_pass_cols_kernel<R, B1, true, REAL>, hipFuncAttributeMaxDynamicSharedMemorySize, cl);
         done = true;
     }
     const dim3 grid((unsigned) (rows * 2 * B1));          // L1 / 16 row groups = 1024 / NC column blocks = 2 B1 per transform
-    constexpr long long full_row_b = 2LL * L * sizeof(R);
+    constexpr int ext_b = REAL ? (int) sizeof(R) : (int) sizeof(C);           // bytes per external time-domain element
+    constexpr long long full_row_b = (long long) L * sizeof(C);
+    constexpr int out_bins = REAL ? L + 1 : L;
     if (!inverse) {
         hipLaunchKernelGGL((two_pass_rows_kernel<R, B1, false>), grid, dim3(512), rl, stream, (const C *) in, (C *) work, (const C *) tw_full, (R) 1,
-                           in_pitch * (long long) sizeof(R), (int) (in_len * sizeof(R)));
-        hipLaunchKernelGGL((two_pass_cols_kernel<R, B1, false>), grid, dim3(512), cl, stream, (const C *) work, (C *) out, (const C *) tw_full,
-                           (const C *) tw_real, (long long) (L + 1), L + 1);
+                           in_pitch * ext_b, (int) (in_len * ext_b));
+        hipLaunchKernelGGL((two_pass_cols_kernel<R, B1, false, REAL>), grid, dim3(512), cl, stream, (const C *) work, (C *) out, (const C *) tw_full,
+                           (const C *) tw_real, (long long) out_bins, out_bins);
     } else {
-        hipLaunchKernelGGL((two_pass_cols_kernel<R, B1, true>), grid, dim3(512), cl, stream, (const C *) in, (C *) work, (const C *) tw_full,
+        hipLaunchKernelGGL((two_pass_cols_kernel<R, B1, true, REAL>), grid, dim3(512), cl, stream, (const C *) in, (C *) work, (const C *) tw_full,
                            (const C *) tw_real, in_pitch, in_len);
         hipLaunchKernelGGL((two_pass_rows_kernel<R, B1, true>), grid, dim3(512), rl, stream, (const C *) work, (C *) out, (const C *) tw_full,
-                           (R) (1.0 / (double) L), full_row_b, (int) full_row_b);                 // 2/(2n), dsc_fft.h:232
+                           (R) (1.0 / (double) L), full_row_b, (int) full_row_b);                 // 2/(2n) (dsc_fft.h:232) = 1/n (:168-175)
     }
 }
 
-template<typename R>
+template<typename R, bool REAL>
 void launch_len(int L, const void *in, void *out, long long rows, void *work, const void *tw_full, const void *tw_real, bool inverse,
                 long long in_pitch, int in_len, hipStream_t stream) {
     switch (L) {
-        case 32768:  launch_pair<R, 1>(in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream); break;
-        case 65536:  launch_pair<R, 2>(in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream); break;
-        case 131072: launch_pair<R, 4>(in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream); break;
-        default:     launch_pair<R, 8>(in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream); break;
+        case 32768:  launch_pair<R, 1, REAL>(in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream); break;
+        case 65536:  launch_pair<R, 2, REAL>(in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream); break;
+        case 131072: launch_pair<R, 4, REAL>(in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream); break;
+        default:     launch_pair<R, 8, REAL>(in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream); break;
     }
 }
 
@@ -383,6 +394,14 @@ bool dsc_fft_two_pass_supports(int L, bool single_precision) {
 void dsc_launch_rfft_two_pass(const void *in, void *out, long long rows, int L, bool inverse, bool single_precision, void *work,
                               const void *tw_full, const void *tw_real, long long in_pitch, int in_len, hipStream_t stream) {
     if (rows <= 0) return;
-    if (single_precision) launch_len<float>(L, in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream);
-    else                  launch_len<double>(L, in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream);
+    if (single_precision) launch_len<float, true>(L, in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream);
+    else                  launch_len<double, true>(L, in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream);
+}
+
+// complex transforms of the same lengths: in = [rows][in_pitch] complex of which in_len <= L are transformed, out = [rows][L]
+void dsc_launch_fft_two_pass(const void *in, void *out, long long rows, int L, bool inverse, bool single_precision, void *work,
+                             const void *tw_full, long long in_pitch, int in_len, hipStream_t stream) {
+    if (rows <= 0) return;
+    if (single_precision) launch_len<float, false>(L, in, out, rows, work, tw_full, tw_full, inverse, in_pitch, in_len, stream);
+    else                  launch_len<double, false>(L, in, out, rows, work, tw_full, tw_full, inverse, in_pitch, in_len, stream);
 }

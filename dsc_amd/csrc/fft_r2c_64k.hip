@@ -207,7 +207,10 @@ __device__ __forceinline__ int thread_id(int wave_sgpr) {
 // Row data is touched exactly once: non-temporal (aux = 2, `nt`) loads and stores keep it from
 // displacing the tables and the next rows in L2 (measured +3.8 % on the rfft kernel).  The
 // filter spectrum H is re-read by every row and stays on the default policy.
-constexpr int kStream = 2;
+#ifndef DSC_STREAM_AUX
+#define DSC_STREAM_AUX 2
+#endif
+constexpr int kStream = DSC_STREAM_AUX;
 __device__ __forceinline__ cf load_c(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return to_cf(__builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, kStream)));
 }

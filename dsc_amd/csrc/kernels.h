@@ -88,6 +88,9 @@ void   dsc_launch_irfft256k_f64(const void *X, double *x, long long rows, void *
 // 65536, 131072, 262144; f32 and f64.  forward: reals -> out = [rows][L + 1] bins; inverse: bins -> [rows][2L] reals.
 // work: rows * L complex of scratch; tw_full: W_L^k, k < L; tw_real: W_{2L}^k, k <= L (the REAL plan's own tables).
 bool   dsc_fft_two_pass_supports(int L, bool single_precision);
+// the same lengths for complex data (dsc_fft / dsc_ifft of complex tensors): in = complex rows, out = [rows][L]
+void   dsc_launch_fft_two_pass(const void *in, void *out, long long rows, int L, bool inverse, bool single_precision, void *work,
+                               const void *tw_full, long long in_pitch, int in_len, hipStream_t stream);
 // in_pitch / in_len: pitch and valid length of the input rows in input elements (reals forward, bins inverse): shorter rows are zero
 // padded, longer ones cropped.
 void   dsc_launch_rfft_two_pass(const void *in, void *out, long long rows, int L, bool inverse, bool single_precision, void *work,

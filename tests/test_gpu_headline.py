@@ -445,3 +445,25 @@ def test_two_pass_padded_rows(dsc, dt, n):
         b = dsc.irfft(dsc.from_numpy(Y), n=bins)
         assert dsc.last_fft_path() == 'c2r_2pass_regs'
         assert_close(b.numpy()[0], port.irfft(Y[0], bins), what=f'padded 2-pass irfft bins={bins} lb={lb}')
+
+
+@pytest.mark.parametrize('dt,L', [(np.complex64, 65536), (np.complex64, 262144), (np.complex128, 32768), (np.complex128, 131072)])
+def test_two_pass_complex_transforms(dsc, dt, L):
+    """dsc_fft / dsc_ifft of complex rows longer than one CU's registers: the two-pass kernels without the real pass,
+    full and zero-padded rows."""
+    from oracle import port
+    rng = np.random.default_rng(L)
+    tol = 1e-6 if dt == np.complex64 else 1e-14
+    for rows, ls in ((1, L), (3, L), (2, L - 77), (2, L + 5)):
+        z = (rng.standard_normal((rows, ls)) + 1j * rng.standard_normal((rows, ls))).astype(dt)
+        Z = dsc.fft(dsc.from_numpy(z), n=L)
+        assert dsc.last_fft_path() == 'c2c_2pass_regs'
+        zh = Z.numpy()
+        assert_close(zh[rows - 1], port.fft(z[rows - 1], L), what=f'fft L={L} ls={ls}')
+        zp = np.zeros((rows, L), np.complex128)
+        zp[:, :min(ls, L)] = z[:, :L]
+        assert rel_l2(zh, np.fft.fft(zp, axis=-1)) <= tol
+        back = dsc.ifft(Z)
+        assert dsc.last_fft_path() == 'c2c_2pass_regs'
+        assert_close(back.numpy()[0], port.ifft(zh[0]), what=f'ifft L={L}')
+        assert rel_l2(back.numpy(), zp) <= tol
