@@ -36,8 +36,12 @@ def test_paths_are_the_hand_written_kernels(dsc):
     dsc.rfft(dsc.from_numpy(np.ones((2, 60000), np.float32)))
     assert dsc.last_fft_path() == 'r2c_64k_regs'
     # anything the fast kernels do not cover must still be right through the generic path
-    dsc.rfft(dsc.from_numpy(np.ones((65536, 2), np.float32)), axis=0)
+    dsc.rfft(dsc.from_numpy(np.ones((65536, 2), np.float32)), axis=0)       # strided lines: transposed to the back first
+    assert dsc.last_fft_path() == 'r2c_64k_regs'
+    dsc.rfft(dsc.from_numpy(np.ones((2, 1 << 21), np.float32)))             # beyond the two-pass kernels
     assert dsc.last_fft_path() == 'generic_4step'
+    dsc.rfft(dsc.from_numpy(np.ones((256, 8), np.float32)), axis=0)         # short strided lines
+    assert dsc.last_fft_path() == 'generic_lds'
 
 
 @pytest.mark.parametrize('rows', [1, 2, 17, 255, 257, 600])
@@ -467,3 +471,27 @@ def test_two_pass_complex_transforms(dsc, dt, L):
         assert dsc.last_fft_path() == 'c2c_2pass_regs'
         assert_close(back.numpy()[0], port.ifft(zh[0]), what=f'ifft L={L}')
         assert rel_l2(back.numpy(), zp) <= tol
+
+
+@pytest.mark.parametrize('shape,axis', [((1024, 37), 0), ((3, 4096, 5), 1), ((2, 2, 2048, 3), 2), ((131072, 3), 0)])
+def test_strided_axes_via_transpose(dsc, shape, axis):
+    """Transforms along a non-last axis of 512 points or more run as transpose -> register kernel -> transpose; every
+    transform kind, padded and cropped, against the oracle."""
+    from oracle import port
+    rng = np.random.default_rng(shape[axis])
+    n = shape[axis]
+    x = rng.standard_normal(shape).astype(np.float32)
+    for nn in (-1, n // 2, 2 * n):
+        if 2 * n > 524288 and nn == 2 * n:
+            continue
+        got = dsc.rfft(dsc.from_numpy(x), n=nn, axis=axis)
+        L = (1 << int(np.ceil(np.log2(nn if nn > 0 else n)))) // 2
+        assert (dsc.last_fft_path() in ('generic_lds', 'generic_4step')) == (L < 512), (shape, nn, dsc.last_fft_path())
+        assert_close(got.numpy(), port.rfft(x, nn, axis), what=f'rfft {shape} axis {axis} n={nn}')
+    X = port.rfft(x, -1, axis)
+    assert_close(dsc.irfft(dsc.from_numpy(X), axis=axis).numpy(), port.irfft(X, -1, axis), what=f'irfft {shape} axis {axis}')
+    z = (x + 1j * rng.standard_normal(shape)).astype(np.complex64)
+    assert_close(dsc.fft(dsc.from_numpy(z), axis=axis).numpy(), port.fft(z, -1, axis), what=f'fft {shape} axis {axis}')
+    assert_close(dsc.ifft(dsc.from_numpy(z), axis=axis).numpy(), port.ifft(z, -1, axis), what=f'ifft {shape} axis {axis}')
+    xd = x.astype(np.float64)
+    assert_close(dsc.rfft(dsc.from_numpy(xd), axis=axis).numpy(), port.rfft(xd, -1, axis), what=f'f64 rfft {shape} axis {axis}')
