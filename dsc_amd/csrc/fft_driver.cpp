@@ -489,6 +489,18 @@ extern "C" dsc_tensor *dsc_filter_fft(dsc_ctx *ctx, const dsc_tensor *s, const d
         ctx->last_fft_path = "filter_64k_regs";
         return out;
     }
+    const bool sp_f = s->dtype == DSC_F32 && H->dtype == DSC_C32, dp_f = s->dtype == DSC_F64 && H->dtype == DSC_C64;
+    if ((sp_f || dp_f) && dsc_fft_regs_mid_supports(n / 2, DSC_MODE_R2C_PACKED, sp_f) && n / 2 <= 16384 && (long long) ls * 8 * 64 < (1LL << 30)) {
+        int out_shape[DSC_MAX_DIMS];
+        memcpy(out_shape, s->shape, sizeof(out_shape));
+        out_shape[DSC_MAX_DIMS - 1] = n;
+        out = make_out(ctx, s, out, out_shape, s->dtype);
+        const dsc_fft_plan *plan = dsc_plan_fft(ctx, n / 2, DSC_FFT_REAL, s->dtype);
+        dsc_launch_filter_regs_mid(s->data, H->data, out->data, s->ne / ls, n / 2, sp_f, plan->tw_full, plan->tw_real, ls, ls < n ? ls : n,
+                                   ctx->stream);
+        ctx->last_fft_path = "filter_mid_regs";
+        return out;
+    }
     dsc_tensor *S = dsc_rfft(ctx, s, nullptr, n, -1);
     dsc_tensor *P = dsc_mul(ctx, S, const_cast<dsc_tensor *>(H), nullptr);
     out = dsc_irfft(ctx, P, out, -1, -1);

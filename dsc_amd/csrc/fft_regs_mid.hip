@@ -56,6 +56,88 @@ template<typename R, int B, bool TWO> struct mid_cfg {
 template<typename R, int B, bool TWO>
 constexpr size_t mid_lds_bytes() { return ((size_t) mid_cfg<R, B, TWO>::PLANE + 2 * mid_cfg<R, B, TWO>::TABLE) * sizeof(R); }
 
+// The transform proper, shared by fft_mid_kernel and fft_mid_filter_kernel.  In: v[j1] = z[T j1 + t] of line g (natural
+// register order).  Out: v[i B + p] = bin k = (t + T i) + COLS brev(p) ("column layout").  Ends with an LDS barrier, i.e.
+// the plane is free on return (three-pass) or untouched since the last barrier.
+template<typename R, int B, bool TWO, bool INV>
+__device__ __forceinline__ void mid_passes(cpx<R> (&v)[32], R *plane, const cpx<R> *wtab, const cpx<R> *__restrict__ tw_full, int g, int t,
+                                           int tid) {
+    using C = cpx<R>;
+    using cfg = mid_cfg<R, B, TWO>;
+    constexpr int T = cfg::T, P1 = cfg::P1, P2 = cfg::P2, CPT = cfg::CPT, COLS = cfg::COLS;
+    const int hi = TWO ? 0 : t / B, lo = TWO ? t : t % B;
+    C u[32];
+    if constexpr (!TWO) {
+        // ---- pass 1 over j1, twiddle W_1024^{j2 k1}
+        dft_n<R, INV, 32>(v);
+#pragma unroll
+        for (int k1 = 1; k1 < 32; ++k1) {
+            const C w = wtab[hi * k1];
+            v[brev(k1, 5)] = INV ? cmulc(v[brev(k1, 5)], w) : cmul(v[brev(k1, 5)], w);
+        }
+        // ---- exchange 1: (j2, j3)[k1] -> thread B k1 + j3, [j2]
+        R *wr = plane + (g * T + lo) * P1 + hi;
+        const R *rd = plane + tid * P1;
+#pragma unroll
+        for (int k1 = 0; k1 < 32; ++k1) wr[k1 * B * P1] = v[brev(k1, 5)].x;
+        lds_barrier();
+#pragma unroll
+        for (int m = 0; m < 32; ++m) u[m].x = rd[m];
+        lds_barrier();
+#pragma unroll
+        for (int k1 = 0; k1 < 32; ++k1) wr[k1 * B * P1] = v[brev(k1, 5)].y;
+        lds_barrier();
+#pragma unroll
+        for (int m = 0; m < 32; ++m) u[m].y = rd[m];
+        lds_barrier();
+    } else {
+#pragma unroll
+        for (int m = 0; m < 32; ++m) u[m] = v[m];                   // two-pass: the loaded index j1 is the pass-2 index
+    }
+    // ---- pass 2 over j2 (thread = (k1, j3) = (hi, lo)), twiddle W_L^{j3 k1} W_{32B}^{j3 k2}
+    dft_n<R, INV, 32>(u);
+    {
+        if constexpr (!TWO) {
+            const C tw2_base = tw_full[hi * lo];
+            u[0] = INV ? cmulc(u[0], tw2_base) : cmul(u[0], tw2_base);
+#pragma unroll
+            for (int k2 = 1; k2 < 32; ++k2) {
+                const C w = cmul(tw2_base, wtab[(32 / B) * lo * k2]);
+                u[brev(k2, 5)] = INV ? cmulc(u[brev(k2, 5)], w) : cmul(u[brev(k2, 5)], w);
+            }
+        } else {
+#pragma unroll
+            for (int k2 = 1; k2 < 32; ++k2) {
+                const C w = wtab[lo * k2];                           // W_L^{j3 k2}
+                u[brev(k2, 5)] = INV ? cmulc(u[brev(k2, 5)], w) : cmul(u[brev(k2, 5)], w);
+            }
+        }
+        // ---- last exchange: row = column k' = k1 + 32 k2 (two-pass: k2), col = j3; thread t reads columns t + T i
+        constexpr int CS = TWO ? 1 : 32;
+        R *wr = plane + (g * COLS + hi) * P2 + lo;
+        const R *rd = plane + (g * COLS + t) * P2;
+#pragma unroll
+        for (int k2 = 0; k2 < 32; ++k2) wr[k2 * CS * P2] = u[brev(k2, 5)].x;
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < CPT; ++i)
+#pragma unroll
+            for (int m = 0; m < B; ++m) v[i * B + m].x = rd[i * T * P2 + m];
+        lds_barrier();
+#pragma unroll
+        for (int k2 = 0; k2 < 32; ++k2) wr[k2 * CS * P2] = u[brev(k2, 5)].y;
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < CPT; ++i)
+#pragma unroll
+            for (int m = 0; m < B; ++m) v[i * B + m].y = rd[i * T * P2 + m];
+        lds_barrier();
+    }
+    // ---- last pass over j3: CPT DFTs of B points; v[i B + p] = bin k = (t + T i) + COLS brev(p)
+    dft_columns<R, INV, B>(v, std::make_integer_sequence<int, CPT>{});
+
+}
+
 // MODE: DSC_MODE_C2C, DSC_MODE_R2C_CAST (L reals in), DSC_MODE_R2C_PACKED (forward only), DSC_MODE_C2R_PACKED (inverse only)
 // PAD: input lines have a pitch of in_pitch_b bytes and in_len_b valid bytes; the rest of the transform length reads as zero
 // (zero padding / cropping of dsc_fft / dsc_rfft / dsc_irfft with n != axis length, dsc.cpp:1990-1998, 2125-2133, 2149-2157).
@@ -65,7 +147,7 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
     const cpx<R> *__restrict__ tw_real, R scale, int in_pitch_b, int in_len_b) {
     using C = cpx<R>;
     using cfg = mid_cfg<R, B, TWO>;
-    constexpr int T = cfg::T, L = cfg::L, G = cfg::G, NT = cfg::NT, P1 = cfg::P1, P2 = cfg::P2, SP = cfg::SP, CPT = cfg::CPT;
+    constexpr int T = cfg::T, L = cfg::L, G = cfg::G, NT = cfg::NT, SP = cfg::SP, CPT = cfg::CPT;
     constexpr int COLS = cfg::COLS;
     constexpr int LOGB = ilog2(B);
     constexpr int CB = (int) sizeof(C);
@@ -79,7 +161,6 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
     const long long line0 = (long long) blockIdx.x * G;
     const long long left = n_lines - line0;
     const int n_valid = left < G ? (int) left : G;                  // lines past the end read zeros, their stores are dropped
-    const int hi = TWO ? 0 : t / B, lo = TWO ? t : t % B;
     constexpr int in_pitch = MODE == DSC_MODE_C2R_PACKED ? L + 1 : L;
     constexpr int out_pitch = MODE == DSC_MODE_R2C_PACKED ? L + 1 : L;
     constexpr int IB = MODE == DSC_MODE_R2C_CAST ? (int) sizeof(R) : CB;      // bytes per input element
@@ -152,75 +233,7 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
     }
     __syncthreads();                // twiddle table visible; staging reads done before the plane is reused
 
-    C u[32];
-    if constexpr (!TWO) {
-        // ---- pass 1 over j1, twiddle W_1024^{j2 k1}
-        dft_n<R, INV, 32>(v);
-#pragma unroll
-        for (int k1 = 1; k1 < 32; ++k1) {
-            const C w = wtab[hi * k1];
-            v[brev(k1, 5)] = INV ? cmulc(v[brev(k1, 5)], w) : cmul(v[brev(k1, 5)], w);
-        }
-        // ---- exchange 1: (j2, j3)[k1] -> thread B k1 + j3, [j2]
-        R *wr = plane + (g * T + lo) * P1 + hi;
-        const R *rd = plane + tid * P1;
-#pragma unroll
-        for (int k1 = 0; k1 < 32; ++k1) wr[k1 * B * P1] = v[brev(k1, 5)].x;
-        lds_barrier();
-#pragma unroll
-        for (int m = 0; m < 32; ++m) u[m].x = rd[m];
-        lds_barrier();
-#pragma unroll
-        for (int k1 = 0; k1 < 32; ++k1) wr[k1 * B * P1] = v[brev(k1, 5)].y;
-        lds_barrier();
-#pragma unroll
-        for (int m = 0; m < 32; ++m) u[m].y = rd[m];
-        lds_barrier();
-    } else {
-#pragma unroll
-        for (int m = 0; m < 32; ++m) u[m] = v[m];                   // two-pass: the loaded index j1 is the pass-2 index
-    }
-    // ---- pass 2 over j2 (thread = (k1, j3) = (hi, lo)), twiddle W_L^{j3 k1} W_{32B}^{j3 k2}
-    dft_n<R, INV, 32>(u);
-    {
-        if constexpr (!TWO) {
-            const C tw2_base = tw_full[hi * lo];
-            u[0] = INV ? cmulc(u[0], tw2_base) : cmul(u[0], tw2_base);
-#pragma unroll
-            for (int k2 = 1; k2 < 32; ++k2) {
-                const C w = cmul(tw2_base, wtab[(32 / B) * lo * k2]);
-                u[brev(k2, 5)] = INV ? cmulc(u[brev(k2, 5)], w) : cmul(u[brev(k2, 5)], w);
-            }
-        } else {
-#pragma unroll
-            for (int k2 = 1; k2 < 32; ++k2) {
-                const C w = wtab[lo * k2];                           // W_L^{j3 k2}
-                u[brev(k2, 5)] = INV ? cmulc(u[brev(k2, 5)], w) : cmul(u[brev(k2, 5)], w);
-            }
-        }
-        // ---- last exchange: row = column k' = k1 + 32 k2 (two-pass: k2), col = j3; thread t reads columns t + T i
-        constexpr int CS = TWO ? 1 : 32;
-        R *wr = plane + (g * COLS + hi) * P2 + lo;
-        const R *rd = plane + (g * COLS + t) * P2;
-#pragma unroll
-        for (int k2 = 0; k2 < 32; ++k2) wr[k2 * CS * P2] = u[brev(k2, 5)].x;
-        lds_barrier();
-#pragma unroll
-        for (int i = 0; i < CPT; ++i)
-#pragma unroll
-            for (int m = 0; m < B; ++m) v[i * B + m].x = rd[i * T * P2 + m];
-        lds_barrier();
-#pragma unroll
-        for (int k2 = 0; k2 < 32; ++k2) wr[k2 * CS * P2] = u[brev(k2, 5)].y;
-        lds_barrier();
-#pragma unroll
-        for (int i = 0; i < CPT; ++i)
-#pragma unroll
-            for (int m = 0; m < B; ++m) v[i * B + m].y = rd[i * T * P2 + m];
-        lds_barrier();
-    }
-    // ---- last pass over j3: CPT DFTs of B points; v[i B + p] = bin k = (t + T i) + COLS brev(p)
-    dft_columns<R, INV, B>(v, std::make_integer_sequence<int, CPT>{});
+    mid_passes<R, B, TWO, INV>(v, plane, wtab, tw_full, g, t, tid);
 
     if constexpr (MODE != DSC_MODE_R2C_PACKED) {
 #pragma unroll
@@ -272,6 +285,159 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
             const R ay = stage[L / 2];
             buf_store<STOREP>(C{amx * scale, -ay * scale}, rout, vout, (L / 2) * CB);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused README filterFFT (README.md:113-135) at the mid sizes: y = irfft(rfft(s, 2L) * H), H [L + 1] bins shared by all
+// rows.  Forward passes, packed-real pass on the pair (k, L-k), times (H[k], H[L-k]), inverse pre-pass on the same pair
+// in the same thread, one staging round trip to bring the pairs back to the load layout, inverse passes: the spectrum
+// never leaves the CU.  s rows may be shorter than 2L (zero padded) or longer (cropped).
+template<typename R, int B, bool TWO>
+__global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVES_PER_EU)) void fft_mid_filter_kernel(
+    const R *__restrict__ s, const cpx<R> *__restrict__ H, cpx<R> *__restrict__ y, long long n_lines, const cpx<R> *__restrict__ tw_full,
+    const cpx<R> *__restrict__ tw_real, int in_pitch_b, int in_len_b) {
+    using C = cpx<R>;
+    using cfg = mid_cfg<R, B, TWO>;
+    constexpr int T = cfg::T, L = cfg::L, G = cfg::G, NT = cfg::NT, SP = cfg::SP, CPT = cfg::CPT, COLS = cfg::COLS;
+    constexpr int LOGB = ilog2(B), CB = (int) sizeof(C);
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    R *plane = (R *) lds_raw;
+    C *wtab = (C *) (plane + cfg::PLANE);
+    const int tid = threadIdx.x;
+    const int g = T >= 64 ? __builtin_amdgcn_readfirstlane(tid / T) : tid / T;
+    const int t = tid - g * T;
+    const long long line0 = (long long) blockIdx.x * G;
+    const long long left = n_lines - line0;
+    const int n_valid = left < G ? (int) left : G;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *) ((const char *) s + line0 * in_pitch_b), 0,
+                                                                         (n_valid - 1) * in_pitch_b + in_len_b, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *) (y + line0 * L), 0, n_valid * L * CB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void *) H, 0, (L + 1) * CB, 0x00020000);
+    const int vin = g * in_pitch_b + t * CB, vout = (g * L + t) * CB;
+    R *stage = plane + g * SP;
+    for (int i = tid; i < cfg::TABLE; i += NT) wtab[i] = tw_full[(long long) i * cfg::TABLE_STRIDE];
+
+    C v[32];
+#pragma unroll
+    for (int j1 = 0; j1 < 32; ++j1) {                                     // sample pairs past the valid length read zero
+        const int eoff = (T * j1 + t) * CB;
+        v[j1] = buf_load<kCached>(rin, eoff < in_len_b ? vin : 0x7f000000, T * j1 * CB, R{});
+        if (eoff + CB > in_len_b) v[j1].y = (R) 0;
+    }
+    __syncthreads();
+    mid_passes<R, B, TWO, false>(v, plane, wtab, tw_full, g, t, tid);     // v[i B + p] = Z[(t + T i) + COLS brev(p)]
+
+    // ---- the pair (k, L-k), k = t + T i, i < 16 (plus k = L/2 in thread 0): a = Z[k], b = Z[L-k] through the staging plane
+    const C wbase = tw_real[t];
+    R ax[16], bx[16], amx = (R) 0;
+    R *up = stage + t;                          // up[T i]        = stage[k]
+    R *dn = stage + (L - 15 * T) - t;           // dn[T (15 - i)] = stage[L - k]
+#pragma unroll
+    for (int i = 0; i < CPT; ++i)
+#pragma unroll
+        for (int p = 0; p < B; ++p) up[T * i + COLS * brev(p, LOGB)] = v[i * B + p].x;
+    if (t == 0) stage[L] = v[0].x;
+    lds_barrier();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { ax[i] = up[T * i]; bx[i] = dn[T * (15 - i)]; }
+    if (t == 0) amx = stage[L / 2];
+    lds_barrier();
+#pragma unroll
+    for (int i = 0; i < CPT; ++i)
+#pragma unroll
+        for (int p = 0; p < B; ++p) up[T * i + COLS * brev(p, LOGB)] = v[i * B + p].y;
+    if (t == 0) stage[L] = v[0].y;
+    lds_barrier();
+    // Every staging slot is read by exactly one thread — the one that owns the pair — so the real parts of the results go
+    // back into the same slots at once (no barrier, and only the imaginary parts stay in registers).
+    R zky[16], zmy[16];
+    C zmid = C{(R) 0, (R) 0};
+    const int hm_voff = ((L - 15 * T) - t) * CB;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const R ay = up[T * i], by = dn[T * (15 - i)];
+        const C w = cmul(wbase, C{(R) root64_re(i), (R) root64_im(i)});            // W_2L^{t + T i}
+        // forward: X[k] = s/2 + wq d, X[L-k] = conj(s/2 - wq d), wq = -(i/2) w          (dsc_fft.h:199-225)
+        R sx = ax[i] + bx[i], sy = ay - by, dx = ax[i] - bx[i], dy = ay + by;
+        R wqx = (R) 0.5 * w.y, wqy = (R) -0.5 * w.x;
+        R wdx = dx * wqx - dy * wqy, wdy = dx * wqy + dy * wqx;
+        C xk = C{(R) 0.5 * sx + wdx, (R) 0.5 * sy + wdy};
+        C xm = C{(R) 0.5 * sx - wdx, wdy - (R) 0.5 * sy};
+        if (i == 0 && t == 0) { xk.y = (R) 0; xm.y = (R) 0; }
+        // times the filter
+        C a = cmul(xk, buf_load<kCached>(rh, t * CB, T * i * CB, R{}));
+        C b = cmul(xm, buf_load<kCached>(rh, hm_voff, T * (15 - i) * CB, R{}));
+        if (i == 0 && t == 0) { a.y = (R) 0; b.y = (R) 0; }                         // dsc_fft.h:227-228: real parts only at k = 0, L
+        // inverse: Z'[k] = s/2 + wq' d, Z'[L-k] = conj(s/2 - wq' d), wq' = (i/2) conj(w)  (dsc_fft.h:194-228)
+        sx = a.x + b.x; sy = a.y - b.y; dx = a.x - b.x; dy = a.y + b.y;
+        wqx = (R) 0.5 * w.y; wqy = (R) 0.5 * w.x;
+        wdx = dx * wqx - dy * wqy; wdy = dx * wqy + dy * wqx;
+        up[T * i] = (R) 0.5 * sx + wdx;                                             // Re Z'[k]
+        dn[T * (15 - i)] = (R) 0.5 * sx - wdx;                                      // Re Z'[L-k]
+        zky[i] = (R) 0.5 * sy + wdy;
+        zmy[i] = wdy - (R) 0.5 * sy;
+    }
+    if (t == 0) {                                                         // k = L/2: X = conj Z, then Z' = conj(X H); after the loop: its
+        const R ay = stage[L / 2];                                        // slot is nobody's pair (T * 16 = L/2 belongs to i = 16)
+        const C ym = cmul(C{amx, -ay}, buf_load<kCached>(rh, (L / 2) * CB, 0, R{}));
+        zmid = C{ym.x, -ym.y};
+        stage[L / 2] = zmid.x;
+    }
+    lds_barrier();
+    // ---- back to the load layout of the inverse transform: v[j1] = Z'[T j1 + t]
+#pragma unroll
+    for (int j1 = 0; j1 < 32; ++j1) v[j1].x = up[T * j1];
+    lds_barrier();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { up[T * i] = zky[i]; dn[T * (15 - i)] = zmy[i]; }
+    if (t == 0) stage[L / 2] = zmid.y;
+    lds_barrier();
+#pragma unroll
+    for (int j1 = 0; j1 < 32; ++j1) v[j1].y = up[T * j1];
+    lds_barrier();
+
+    // an opaque copy of the table pointer: otherwise the 62 twiddles the forward passes read from the table are kept in
+    // registers for the inverse passes (common subexpressions) and the kernel needs 220 VGPRs
+    const C *wtab_inv = wtab;
+    asm volatile("" : "+v"(wtab_inv));
+    mid_passes<R, B, TWO, true>(v, plane, wtab_inv, tw_full, g, t, tid);
+    const R scale = (R) (1.0 / (double) L);                               // 2/(2n), dsc_fft.h:232
+#pragma unroll
+    for (int i = 0; i < CPT; ++i)
+#pragma unroll
+        for (int p = 0; p < B; ++p) {
+            const C r = v[i * B + p];
+            buf_store<kStream>(C{r.x * scale, r.y * scale}, rout, vout, (T * i + COLS * brev(p, LOGB)) * CB);
+        }
+}
+
+template<typename R, int B, bool TWO>
+void launch_filter(const void *s, const void *H, void *y, long long n_lines, const void *tw_full, const void *tw_real, int in_pitch_b,
+                   int in_len_b, hipStream_t stream) {
+    using cfg = mid_cfg<R, B, TWO>;
+    constexpr size_t lds = mid_lds_bytes<R, B, TWO>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void) hipFuncSetAttribute((const void *) fft_mid_filter_kernel<R, B, TWO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        attr_set = true;
+    }
+    const long long groups = (n_lines + cfg::G - 1) / cfg::G;
+    hipLaunchKernelGGL((fft_mid_filter_kernel<R, B, TWO>), dim3((unsigned) groups), dim3(cfg::NT), lds, stream, (const R *) s,
+                       (const cpx<R> *) H, (cpx<R> *) y, n_lines, (const cpx<R> *) tw_full, (const cpx<R> *) tw_real, in_pitch_b, in_len_b);
+}
+
+template<typename R>
+void launch_filter_len(int L, const void *s, const void *H, void *y, long long n_lines, const void *tw_full, const void *tw_real,
+                       int pb, int lb, hipStream_t stream) {
+    switch (L) {
+        case 256:   launch_filter<R, 8, true>(s, H, y, n_lines, tw_full, tw_real, pb, lb, stream); break;
+        case 512:   launch_filter<R, 16, true>(s, H, y, n_lines, tw_full, tw_real, pb, lb, stream); break;
+        case 1024:  launch_filter<R, 32, true>(s, H, y, n_lines, tw_full, tw_real, pb, lb, stream); break;
+        case 2048:  launch_filter<R, 2, false>(s, H, y, n_lines, tw_full, tw_real, pb, lb, stream); break;
+        case 4096:  launch_filter<R, 4, false>(s, H, y, n_lines, tw_full, tw_real, pb, lb, stream); break;
+        case 8192:  launch_filter<R, 8, false>(s, H, y, n_lines, tw_full, tw_real, pb, lb, stream); break;
+        default:    launch_filter<R, 16, false>(s, H, y, n_lines, tw_full, tw_real, pb, lb, stream); break;
     }
 }
 
@@ -346,4 +512,14 @@ void dsc_launch_fft_regs_mid(const void *in, void *out, long long n_lines, int L
     } else {
         launch_len<float>(in, out, n_lines, L, mode, inverse, tw_full, tw_real, scale, pb, lb, stream);
     }
+}
+
+// y = irfft(rfft(s, 2L) * H) fused, L = 256 .. 16384: s = [n_lines][in_pitch] reals of which in_len <= 2L are used, H = [L + 1]
+// bins, y = [n_lines][2L] reals
+void dsc_launch_filter_regs_mid(const void *s, const void *H, void *y, long long n_lines, int L, bool single_precision, const void *tw_full,
+                                const void *tw_real, long long in_pitch, int in_len, hipStream_t stream) {
+    if (n_lines <= 0) return;
+    const int rb = single_precision ? 4 : 8;
+    if (single_precision) launch_filter_len<float>(L, s, H, y, n_lines, tw_full, tw_real, (int) (in_pitch * rb), in_len * rb, stream);
+    else                  launch_filter_len<double>(L, s, H, y, n_lines, tw_full, tw_real, (int) (in_pitch * rb), in_len * rb, stream);
 }

@@ -105,6 +105,11 @@ bool dsc_fft_regs_mid_supports(int L, dsc_fft_mode mode, bool single_precision);
 void dsc_launch_fft_regs_mid(const void *in, void *out, long long n_lines, int L, dsc_fft_mode mode, bool inverse, bool single_precision,
                              const void *tw_full, const void *tw_real, double scale, long long in_pitch, int in_len, hipStream_t stream);
 
+// fused y = irfft(rfft(s, 2L) * H) at the same lengths (README filterFFT): s = [n_lines][in_pitch] reals of which in_len <= 2L are
+// used, H = [L + 1] bins shared by all rows, y = [n_lines][2L] reals
+void dsc_launch_filter_regs_mid(const void *s, const void *H, void *y, long long n_lines, int L, bool single_precision, const void *tw_full,
+                                const void *tw_real, long long in_pitch, int in_len, hipStream_t stream);
+
 // ---- element-wise ------------------------------------------------------------------------
 // dtype codes are dsc_dtype values (0 f32, 1 f64, 2 c32, 3 c64)
 void dsc_launch_cast(const void *in, int in_dtype, void *out, int out_dtype, long long ne, hipStream_t stream);

@@ -495,3 +495,30 @@ def test_strided_axes_via_transpose(dsc, shape, axis):
     assert_close(dsc.ifft(dsc.from_numpy(z), axis=axis).numpy(), port.ifft(z, -1, axis), what=f'ifft {shape} axis {axis}')
     xd = x.astype(np.float64)
     assert_close(dsc.rfft(dsc.from_numpy(xd), axis=axis).numpy(), port.rfft(xd, -1, axis), what=f'f64 rfft {shape} axis {axis}')
+
+
+@pytest.mark.parametrize('dt', [np.float32, np.float64])
+@pytest.mark.parametrize('n', [512, 2048, 8192, 32768])
+def test_fused_filter_mid_sizes(dsc, dt, n):
+    """dsc_filter_fft (README.md:113-135 as one call) on the fused mid-size kernel: y = irfft(rfft(s, n) * H) against the
+    oracle's three-operator composition, full rows, zero-padded rows (the README pads s inside rfft) and ragged row counts."""
+    from oracle import port
+    rng = np.random.default_rng(n)
+    taps = np.zeros(n, dt)
+    taps[:61] = rng.standard_normal(61)
+    H = port.rfft(taps)
+    tH = dsc.from_numpy(H)
+    for rows, ls in ((1, n), (7, n), (5, n - 61), (3, n // 2 + 1), (2, n + 10)):
+        s = rng.standard_normal((rows, ls)).astype(dt)
+        y = dsc.filter_fft(dsc.from_numpy(s), tH)
+        assert dsc.last_fft_path() == 'filter_mid_regs', (n, ls)
+        assert y.shape == (rows, n)
+        yh = y.numpy()
+        for r in (0, rows - 1):
+            want = port.irfft(port.mul(port.rfft(s[r], n), H))
+            assert_close(yh[r], want, what=f'filter n={n} ls={ls} row {r}')
+    # linear convolution check (the README's use): y[:ls + lb - 1] == convolve(s, b)
+    s = rng.standard_normal((2, n - 61 + 1)).astype(dt)
+    y = dsc.filter_fft(dsc.from_numpy(s), tH)[:, :n].numpy()
+    want = np.stack([np.convolve(r.astype(np.float64), taps[:61].astype(np.float64)) for r in s])
+    assert np.abs(y - want).max() <= (2e-3 if dt == np.float32 else 1e-10)
