@@ -522,3 +522,36 @@ def test_fused_filter_mid_sizes(dsc, dt, n):
     y = dsc.filter_fft(dsc.from_numpy(s), tH)[:, :n].numpy()
     want = np.stack([np.convolve(r.astype(np.float64), taps[:61].astype(np.float64)) for r in s])
     assert np.abs(y - want).max() <= (2e-3 if dt == np.float32 else 1e-10)
+
+
+@pytest.mark.parametrize('dt', [np.float32, np.float64])
+def test_every_power_of_two_length(dsc, dt):
+    """One sweep over every transform length 2 .. 2^20, all four transforms, full and zero-padded rows,
+    against float64 numpy: whatever kernel path a length takes, the result must be within the precision's tolerance."""
+    cdt = np.complex64 if dt == np.float32 else np.complex128
+    tol = 2e-6 if dt == np.float32 else 2e-14
+    rng = np.random.default_rng(11)
+    paths = {}
+    for p in range(1, 21):
+        n = 1 << p
+        rows = 3 if n <= 1 << 17 else 1
+        for ls in (n, max(1, n - 3)):
+            x = rng.standard_normal((rows, ls)).astype(dt)
+            xp = np.zeros((rows, n), np.float64)
+            xp[:, :ls] = x
+            X = dsc.rfft(dsc.from_numpy(x), n=n)
+            paths.setdefault(dsc.last_fft_path(), []).append(n)
+            want = np.fft.rfft(xp, axis=-1)
+            assert rel_l2(X.numpy(), want) <= tol, ('rfft', n, ls, dsc.last_fft_path())
+            if n >= 2:
+                back = dsc.irfft(X).numpy()
+                assert back.shape == (rows, n) and rel_l2(back, xp) <= tol, ('irfft', n, ls, dsc.last_fft_path())
+            z = (rng.standard_normal((rows, ls)) + 1j * rng.standard_normal((rows, ls))).astype(cdt)
+            zp = np.zeros((rows, n), np.complex128)
+            zp[:, :ls] = z
+            Z = dsc.fft(dsc.from_numpy(z), n=n)
+            assert rel_l2(Z.numpy(), np.fft.fft(zp, axis=-1)) <= tol, ('fft', n, ls, dsc.last_fft_path())
+            assert rel_l2(dsc.ifft(Z).numpy(), zp) <= tol, ('ifft', n, ls, dsc.last_fft_path())
+    # every kernel family must have been exercised by the sweep
+    need = {'generic_lds', 'regs_mid', 'r2c_2pass_regs', 'generic_4step'} | ({'r2c_64k_regs'} if dt == np.float32 else set())
+    assert need <= set(paths), paths.keys()
