@@ -94,9 +94,7 @@ extern "C" dsc_fft_plan *dsc_plan_fft(dsc_ctx *ctx, int n, dsc_fft_type fft_type
     const bool regs64k = fft_type == DSC_FFT_REAL && twd == DSC_F32 && fft_n == 32768;
     const size_t full_bytes = DSC_ALIGN_UP((size_t) fft_n * 2 * real_sz, DSC_DEVICE_ALIGN);
     const size_t real_bytes = fft_type == DSC_FFT_REAL ? DSC_ALIGN_UP(((size_t) fft_n + 1) * 2 * real_sz, DSC_DEVICE_ALIGN) : 0;
-    const bool regs256k = fft_type == DSC_FFT_REAL && twd == DSC_F64 && fft_n == 131072;
-    const size_t aux_bytes = regs64k ? DSC_ALIGN_UP(dsc_r2c64k_table_bytes(), DSC_DEVICE_ALIGN)
-                           : regs256k ? DSC_ALIGN_UP(dsc_r2c256k_table_bytes(), DSC_DEVICE_ALIGN) : 0;
+    const size_t aux_bytes = regs64k ? DSC_ALIGN_UP(dsc_r2c64k_table_bytes(), DSC_DEVICE_ALIGN) : 0;
     const size_t total = full_bytes + real_bytes + aux_bytes;
 
     std::vector<char> host(total, 0);
@@ -108,7 +106,6 @@ extern "C" dsc_fft_plan *dsc_plan_fft(dsc_ctx *ctx, int n, dsc_fft_type fft_type
         if (real_bytes) fill_roots((double *) (host.data() + full_bytes), (long long) fft_n + 1, 2LL * fft_n);
     }
     if (regs64k) dsc_r2c64k_build_tables(host.data() + full_bytes + real_bytes);
-    if (regs256k) dsc_r2c256k_build_tables(host.data() + full_bytes + real_bytes);
 
     plan = new dsc_fft_plan();
     plan->n = fft_n;
@@ -291,9 +288,8 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
         }
     }
 
-    // long real transforms of contiguous full rows (config 5 = f64 N = 262144): two passes over HBM, rows kernel + column
-    // kernel with the real pass fused (fft_r2c_2pass.hip).  DSC_C5_3PASS=1 selects the first, three-pass version of the
-    // f64 262144-point case for A/B.
+    // long transforms of contiguous rows (config 5 = f64 N = 262144): two passes over HBM, rows kernel + column kernel with
+    // the real pass fused (fft_r2c_2pass.hip)
     static const bool two_pass_off = getenv("DSC_NO_TWO_PASS") != nullptr;        // A/B aid (tools/bench_mid.py)
     if ((packed || j.mode == DSC_MODE_C2C) && inner == 1 && !two_pass_off && dsc_fft_two_pass_supports(j.L, sp)) {
         const int L = j.L;
@@ -301,8 +297,6 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
         const bool fwd = cplx ? !j.inverse : j.mode == DSC_MODE_R2C_PACKED, inv = !fwd;   // any row length: padded / cropped by the row descriptors
         const long long x_n = j.x->shape[j.slot];
         {
-            static const bool three_pass_env = getenv("DSC_C5_3PASS") != nullptr;
-            const bool three_pass = three_pass_env && !cplx && !sp && L == 131072 && plan->tw_aux != nullptr && x_n == (fwd ? 2 * L : L + 1);
             const size_t csz = sp ? 8 : 16;
             const size_t row_bytes = (size_t) L * csz;
             const size_t real_row = cplx ? (size_t) (fwd ? x_n : L) * csz : (size_t) (fwd ? x_n : 2 * L) * (csz / 2);       // time-domain side
@@ -311,12 +305,11 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
             long long chunk = (long long) ((ctx->scratch.capacity() - DSC_DEVICE_ALIGN) / row_bytes);
             if (chunk < 1) DSC_LOG_FATAL("scratch arena too small: a %d-point transform needs %.1f MB of scratch per row", 2 * L, row_bytes / 1048576.);
             {
-                // rows per launch sequence: as many as the scratch arena holds (the two-pass kernels lose 15 % when cut into
-                // 64-row launches; the three-pass version gained 4-9 % from keeping its work buffer in the Infinity Cache)
+                // rows per launch sequence: as many as the scratch arena holds (cutting the batch into 64-row launches costs 15 %)
                 static long long cap_rows = -1;
                 if (cap_rows < 0) {
-                    const char *e = getenv("DSC_C5_CHUNK_ROWS");
-                    cap_rows = e ? atoll(e) : (three_pass_env ? 64 : (1LL << 40));
+                    const char *e = getenv("DSC_2PASS_CHUNK_ROWS");
+                    cap_rows = e ? atoll(e) : (1LL << 40);
                     if (cap_rows < 1) cap_rows = 1;
                 }
                 if (chunk > cap_rows) chunk = cap_rows;
@@ -329,12 +322,8 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
                 char *dst = (char *) j.out->data + (size_t) q * (fwd ? bins_row : real_row);
                 if (cplx)
                     dsc_launch_fft_two_pass(src, dst, nl, L, inv, sp, work, plan->tw_full, x_n, j.in_len, ctx->stream);
-                else if (!three_pass)
-                    dsc_launch_rfft_two_pass(src, dst, nl, L, inv, sp, work, plan->tw_full, plan->tw_real, x_n, j.in_len, ctx->stream);
-                else if (fwd)
-                    dsc_launch_rfft256k_f64((const double *) src, dst, nl, work, plan->tw_aux, plan->tw_real, ctx->n_cu, ctx->stream);
                 else
-                    dsc_launch_irfft256k_f64(src, (double *) dst, nl, work, plan->tw_aux, plan->tw_real, ctx->n_cu, ctx->stream);
+                    dsc_launch_rfft_two_pass(src, dst, nl, L, inv, sp, work, plan->tw_full, plan->tw_real, x_n, j.in_len, ctx->stream);
             }
             ctx->last_fft_path = cplx ? "c2c_2pass_regs" : fwd ? "r2c_2pass_regs" : "c2r_2pass_regs";
             return;

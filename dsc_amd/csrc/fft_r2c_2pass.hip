@@ -17,8 +17,7 @@
 //                set of a workgroup is S_b = [H b + 1, H b + H] (H = NC / 2) plus its mirror M_b, closed under that
 //                pairing (column 0, which pairs with itself, takes the place of the duplicate 512 in the last
 //                block); partners meet through an LDS staging plane, one component at a time.
-// Twice the algorithmic traffic (the ceiling is half the copy rate); a three-pass version of the f64 262144-point
-// case is kept in fft_r2c_256k_f64.hip for A/B.  The inverse runs the same two kernels backwards.
+// Twice the algorithmic traffic (the ceiling is half the copy rate).  The inverse runs the same two kernels backwards.
 // Reference: dsc_rfft / dsc_irfft (dsc/src/dsc.cpp:2102-2260, dsc_fft.h:57-238).
 #include "kernels.h"
 

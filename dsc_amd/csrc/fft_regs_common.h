@@ -1,5 +1,5 @@
 // fft_regs_common.h — device building blocks of the register-resident FFT kernels (fft_regs_mid.hip,
-// fft_r2c_256k_f64_2pass.hip): complex arithmetic, in-register radix-2 DIF DFTs of 2..32 points with
+// fft_r2c_2pass.hip): complex arithmetic, in-register radix-2 DIF DFTs of 2..32 points with
 // compile-time twiddles (results in bit-reversed register order), the LDS-only barrier and buffer
 // load / store wrappers.  Header-only, everything in an anonymous namespace.
 #pragma once

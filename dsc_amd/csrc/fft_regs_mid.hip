@@ -3,7 +3,7 @@
 // complex data, B = 32 (L = 32768), f32.
 // The same kernels in f64 for L = 256 .. 16384.
 //
-// The design of fft_r2c_64k.hip / fft_r2c_256k_f64.hip, parameterised by B: a line lives in
+// The design of fft_r2c_64k.hip, parameterised by B: a line lives in
 // the registers of T = 32 B threads, 32 complex each; G = 16/B (or 8/B) lines share a
 // workgroup.  One HBM round trip:
 //

@@ -74,16 +74,6 @@ void   dsc_launch_irfft64k(const void *X, float *x, int batch, const void *aux, 
 void   dsc_launch_filter64k(const float *s, const void *H, float *y, int batch, int in_pitch, int in_len, const void *aux, int n_cu,
                             hipStream_t stream);
 
-// ---- 262144-point real transforms in f64 (config 5): radix-8 pass + register-resident 16384-point
-// c64 FFTs + post-pass (fft_r2c_256k_f64.hip).  x: [rows][262144] f64, X: [rows][131073] c64,
-// work: rows * 2 MiB of scratch, aux: tables from dsc_r2c256k_build_tables, tw_real: W_{2L}^k, k <= L.
-size_t dsc_r2c256k_table_bytes();
-void   dsc_r2c256k_build_tables(void *host_dst);
-void   dsc_launch_rfft256k_f64(const double *x, void *X, long long rows, void *work, const void *aux, const void *tw_real,
-                               int n_cu, hipStream_t stream);
-void   dsc_launch_irfft256k_f64(const void *X, double *x, long long rows, void *work, const void *aux, const void *tw_real,
-                                int n_cu, hipStream_t stream);
-
 // ---- long real transforms in two passes over HBM (fft_r2c_2pass.hip): packed complex length L = 32768 (f64 only),
 // 65536, 131072, 262144; f32 and f64.  forward: reals -> out = [rows][L + 1] bins; inverse: bins -> [rows][2L] reals.
 // work: rows * L complex of scratch; tw_full: W_L^k, k < L; tw_real: W_{2L}^k, k <= L (the REAL plan's own tables).
