@@ -555,3 +555,17 @@ def test_every_power_of_two_length(dsc, dt):
     # every kernel family must have been exercised by the sweep
     need = {'generic_lds', 'regs_mid', 'r2c_2pass_regs', 'generic_4step'} | ({'r2c_64k_regs'} if dt == np.float32 else set())
     assert need <= set(paths), paths.keys()
+
+
+def test_rccl_sees_arena_memory_one_rank():
+    """bench.py's all-gather phase hands RCCL zero-copy views of arena memory: with a one-rank NCCL (= RCCL) group on the
+    test box's single GPU the view goes through all_gather_into_tensor, all_reduce and barrier and comes back intact
+    (tools/check_rccl_view.py).  More ranks need more GPUs."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29613')
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_rccl_view.py')], capture_output=True, text=True, timeout=300,
+                       cwd=root, env=env)
+    assert r.returncode == 0 and 'OK' in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
