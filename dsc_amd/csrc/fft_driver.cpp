@@ -281,8 +281,9 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
             ctx->last_fft_path = "r2c_64k_regs";
             return;
         }
-        if (j.mode == DSC_MODE_C2R_PACKED && j.in_len == 32769 && j.x->shape[j.slot] == 32769) {
-            dsc_launch_irfft64k(j.x->data, (float *) j.out->data, (int) n_lines, plan->tw_aux, ctx->n_cu, ctx->stream);
+        if (j.mode == DSC_MODE_C2R_PACKED) {
+            dsc_launch_irfft64k(j.x->data, (float *) j.out->data, (int) n_lines, j.x->shape[j.slot], j.in_len, plan->tw_aux, ctx->n_cu,
+                                ctx->stream);
             ctx->last_fft_path = "c2r_64k_regs";
             return;
         }

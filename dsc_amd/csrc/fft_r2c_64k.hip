@@ -551,8 +551,9 @@ __device__ __forceinline__ void unzip_rows_outer_first(cf (&v)[32]) {
 // post-pass, the packed-real pre-pass pairs them through ds_bpermute, and three
 // conjugate-twiddle passes end with thread t holding z[t + 1024 r]: the time samples leave as
 // aligned, coalesced 8-B stores.  The 2/(2n) scale is folded into the pre-pass constants.
+// in_pitch: bins between input rows; in_len <= 32769 bins per row are used, missing ones read as zero (dsc.cpp:2149-2157)
 __global__ __launch_bounds__(1024) void irfft64k_kernel(const f2 *__restrict__ X, float *__restrict__ x, int batch,
-                                                        const f2 *__restrict__ aux) {
+                                                        const f2 *__restrict__ aux, int in_pitch, int in_len) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *plane = lds;
     f2 *w1024 = (f2 *) (lds + kPlaneFloats);
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(1024) void irfft64k_kernel(const f2 *__restrict__ X
     {
         const int row0 = blockIdx.x;
         const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(
-            (void *) (X + (size_t) row0 * (kM + 1)), 0, row0 < batch ? (kM + 1) * 8 : 0, 0x00020000);
+            (void *) (X + (size_t) row0 * in_pitch), 0, row0 < batch ? in_len * 8 : 0, 0x00020000);
         const int t0 = thread_id(wave_sgpr);
         const int c = column_of(t0 >> 6, t0 & 63);
 #pragma unroll
@@ -582,7 +583,7 @@ __global__ __launch_bounds__(1024) void irfft64k_kernel(const f2 *__restrict__ X
     for (int row = blockIdx.x; row < batch; row += gridDim.x) {
         const int next_row = row + gridDim.x;
         const __amdgpu_buffer_rsrc_t rnext = __builtin_amdgcn_make_buffer_rsrc(
-            (void *) (X + (size_t) next_row * (kM + 1)), 0, next_row < batch ? (kM + 1) * 8 : 0, 0x00020000);
+            (void *) (X + (size_t) next_row * in_pitch), 0, next_row < batch ? in_len * 8 : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t rout =
             __builtin_amdgcn_make_buffer_rsrc((void *) (x + (size_t) row * 65536), 0, 65536 * 4, 0x00020000);
 
@@ -766,7 +767,7 @@ void dsc_launch_rfft64k(const float *x, void *X, int batch, int in_pitch, int in
     hipLaunchKernelGGL(rfft64k_kernel, dim3(grid), dim3(1024), kLdsBytes, stream, x, (f2 *) X, batch, (const f2 *) aux, in_pitch, in_len PROBE_NULL);
 }
 
-void dsc_launch_irfft64k(const void *X, float *x, int batch, const void *aux, int n_cu, hipStream_t stream) {
+void dsc_launch_irfft64k(const void *X, float *x, int batch, int in_pitch, int in_len, const void *aux, int n_cu, hipStream_t stream) {
     if (batch <= 0) return;
     static bool attr_set = false;
     if (!attr_set) {
@@ -774,7 +775,7 @@ void dsc_launch_irfft64k(const void *X, float *x, int batch, const void *aux, in
         attr_set = true;
     }
     const int grid = batch < n_cu ? batch : n_cu;
-    hipLaunchKernelGGL(irfft64k_kernel, dim3(grid), dim3(1024), kLdsBytes, stream, (const f2 *) X, x, batch, (const f2 *) aux);
+    hipLaunchKernelGGL(irfft64k_kernel, dim3(grid), dim3(1024), kLdsBytes, stream, (const f2 *) X, x, batch, (const f2 *) aux, in_pitch, in_len);
 }
 void dsc_launch_filter64k(const float *s, const void *H, float *y, int batch, int in_pitch, int in_len, const void *aux, int n_cu,
                           hipStream_t stream) {

@@ -69,7 +69,7 @@ size_t dsc_r2c64k_table_bytes();
 void   dsc_r2c64k_build_tables(void *host_dst);          // fills a host staging buffer of table_bytes
 // in_pitch: floats between input rows; in_len <= 65536 valid samples per row, the rest reads as zero (zero padding / crop)
 void   dsc_launch_rfft64k(const float *x, void *X, int batch, int in_pitch, int in_len, const void *aux, int n_cu, hipStream_t stream);
-void   dsc_launch_irfft64k(const void *X, float *x, int batch, const void *aux, int n_cu, hipStream_t stream);
+void   dsc_launch_irfft64k(const void *X, float *x, int batch, int in_pitch, int in_len, const void *aux, int n_cu, hipStream_t stream);   // pitch / valid length in bins
 // y = irfft(rfft(s) * H) fused; H: [32769] c32
 void   dsc_launch_filter64k(const float *s, const void *H, float *y, int batch, int in_pitch, int in_len, const void *aux, int n_cu,
                             hipStream_t stream);

@@ -396,6 +396,12 @@ def test_padded_and_cropped_rows_on_the_register_kernels(dsc, ls):
     assert dsc.last_fft_path() == 'filter_64k_regs' and y.shape == (rows, N)
     want = port.irfft(port.mul(port.rfft(x[1], N), H))
     assert_close(y.numpy()[1], want, what=f'padded filter ls={ls}')
+    # irfft with fewer / more bins than n/2 + 1 (`n` counts bins, dsc.cpp:2199-2200)
+    lb = min(max(ls // 2, 2), 40000)
+    Y = (rng.standard_normal((rows, lb)) + 1j * rng.standard_normal((rows, lb))).astype(np.complex64)
+    b = dsc.irfft(dsc.from_numpy(Y), n=N // 2 + 1)
+    assert dsc.last_fft_path() == 'c2r_64k_regs'
+    assert_close(b.numpy()[rows - 1], port.irfft(Y[rows - 1], N // 2 + 1), what=f'padded irfft lb={lb}')
 
 
 @pytest.mark.parametrize('dt', [np.float32, np.float64])
