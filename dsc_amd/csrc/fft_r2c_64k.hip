@@ -553,7 +553,7 @@ __device__ __forceinline__ void unzip_rows_outer_first(cf (&v)[32]) {
 // aligned, coalesced 8-B stores.  The 2/(2n) scale is folded into the pre-pass constants.
 // in_pitch: bins between input rows; in_len <= 32769 bins per row are used, missing ones read as zero (dsc.cpp:2149-2157)
 __global__ __launch_bounds__(1024) void irfft64k_kernel(const f2 *__restrict__ X, float *__restrict__ x, int batch,
-                                                        const f2 *__restrict__ aux, int in_pitch, int in_len) {
+                                                        const f2 *__restrict__ aux, int in_pitch, int in_len PROBE_ARGS) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *plane = lds;
     f2 *w1024 = (f2 *) (lds + kPlaneFloats);
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(1024) void irfft64k_kernel(const f2 *__restrict__ X
     {
         const int row0 = blockIdx.x;
         const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(
-            (void *) (X + (size_t) row0 * in_pitch), 0, row0 < batch ? in_len * 8 : 0, 0x00020000);
+            (void *) (X + (size_t) row0 * in_pitch), 0, row0 < batch ? in_len * 8 * IO_ON : 0, 0x00020000);
         const int t0 = thread_id(wave_sgpr);
         const int c = column_of(t0 >> 6, t0 & 63);
 #pragma unroll
@@ -583,9 +583,9 @@ __global__ __launch_bounds__(1024) void irfft64k_kernel(const f2 *__restrict__ X
     for (int row = blockIdx.x; row < batch; row += gridDim.x) {
         const int next_row = row + gridDim.x;
         const __amdgpu_buffer_rsrc_t rnext = __builtin_amdgcn_make_buffer_rsrc(
-            (void *) (X + (size_t) next_row * in_pitch), 0, next_row < batch ? in_len * 8 : 0, 0x00020000);
+            (void *) (X + (size_t) next_row * in_pitch), 0, next_row < batch ? in_len * 8 * IO_ON : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t rout =
-            __builtin_amdgcn_make_buffer_rsrc((void *) (x + (size_t) row * 65536), 0, 65536 * 4, 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc((void *) (x + (size_t) row * 65536), 0, 65536 * 4 * IO_ON, 0x00020000);
 
         inverse_prepass(v, y_last, aux, wave_sgpr);
         three_passes<true>(v, plane, w1024, aux, wave_sgpr, true, false);      // v[p] = z[t + 1024 br5(p)]
@@ -775,7 +775,7 @@ void dsc_launch_irfft64k(const void *X, float *x, int batch, int in_pitch, int i
         attr_set = true;
     }
     const int grid = batch < n_cu ? batch : n_cu;
-    hipLaunchKernelGGL(irfft64k_kernel, dim3(grid), dim3(1024), kLdsBytes, stream, (const f2 *) X, x, batch, (const f2 *) aux, in_pitch, in_len);
+    hipLaunchKernelGGL(irfft64k_kernel, dim3(grid), dim3(1024), kLdsBytes, stream, (const f2 *) X, x, batch, (const f2 *) aux, in_pitch, in_len PROBE_NULL);
 }
 void dsc_launch_filter64k(const float *s, const void *H, float *y, int batch, int in_pitch, int in_len, const void *aux, int n_cu,
                           hipStream_t stream) {

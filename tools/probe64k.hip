@@ -41,5 +41,18 @@ int main(int argc, char **argv) {
         CK(hipEventElapsedTime(&ms, e0, e1));
         printf("%s: %.3f ms per launch of %d rows\n", io_on ? "whole kernel          " : "global accesses dropped", ms / 20, batch);
     }
+    CK(hipFuncSetAttribute((const void *) irfft64k_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    for (int io_on = 1; io_on >= 0; --io_on) {
+        for (int rep = 0; rep < 60; ++rep)
+            hipLaunchKernelGGL(irfft64k_kernel, dim3(256), dim3(1024), kLdsBytes, 0, X, x, batch, aux, 32769, 32769, io_on);
+        CK(hipEventRecord(e0));
+        for (int rep = 0; rep < 20; ++rep)
+            hipLaunchKernelGGL(irfft64k_kernel, dim3(256), dim3(1024), kLdsBytes, 0, X, x, batch, aux, 32769, 32769, io_on);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("irfft %s: %.3f ms per launch of %d rows\n", io_on ? "whole kernel          " : "global accesses dropped", ms / 20, batch);
+    }
     return 0;
 }
