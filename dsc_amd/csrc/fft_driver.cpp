@@ -333,6 +333,16 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
 
     // register-resident mid sizes: contiguous full lines along the last axis
     static const bool regs_mid_off = getenv("DSC_NO_REGS_MID") != nullptr;      // A/B aid (tools/bench_mid.py)
+    if (inner == 1 && !regs_mid_off && dsc_fft_regs_small_supports(j.L)) {            // 32 .. 256 points: LDS-staged register kernel
+        const int x_n = j.x->shape[j.slot];
+        const int want = j.mode == DSC_MODE_R2C_PACKED ? 2 * j.L : j.mode == DSC_MODE_C2R_PACKED ? j.L + 1 : j.L;
+        if (j.in_len == want && x_n == want) {
+            dsc_launch_fft_regs_mid(j.x->data, j.out->data, n_lines, j.L, j.mode, j.inverse, sp, plan->tw_full, plan->tw_real, j.scale, -1, 0,
+                                    ctx->stream);
+            ctx->last_fft_path = "regs_small";
+            return;
+        }
+    }
     if (inner == 1 && !regs_mid_off && dsc_fft_regs_mid_supports(j.L, j.mode, sp)) {
         const int x_n = j.x->shape[j.slot];
         const int want = j.mode == DSC_MODE_R2C_PACKED ? 2 * j.L : j.mode == DSC_MODE_C2R_PACKED ? j.L + 1 : j.L;

@@ -47,7 +47,10 @@ template<typename R, int B, bool TWO> struct mid_cfg {
     static constexpr int P1 = 33;                    // exchange-1 row pitch (values): odd
     static constexpr int P2 = B + 1;                 // last-exchange row pitch
     static constexpr int SP = L + 1;                 // staging pitch per line (bins 0 .. L)
-    static constexpr int PLANE = G * COLS * P2;      // >= G*T*P1 (three-pass) and >= G*SP
+    // values per line in the last exchange.  Two-pass: padded so that the stride is = B mod 64 — the lanes of a wave are
+    // (line, j3) pairs and then hit 64 different banks (an unpadded 32 (B + 1) is = 32 mod 64: up to 16-way conflicts)
+    static constexpr int LSTRIDE = TWO ? 32 * (B + 1) + (((B - 32 - 32 * B) % 64) + 64) % 64 : 1024 * (B + 1);
+    static constexpr int PLANE = G * LSTRIDE;        // >= G*T*P1 (three-pass) and >= G*SP
     static constexpr int CPT = 32 / B;               // columns per thread in the last pass
     static constexpr int TABLE = TWO ? L : 1024;     // LDS twiddle table: W_L^m (two-pass) or W_1024^m
     static constexpr int TABLE_STRIDE = TWO ? 1 : B;
@@ -64,7 +67,7 @@ __device__ __forceinline__ void mid_passes(cpx<R> (&v)[32], R *plane, const cpx<
                                            int tid) {
     using C = cpx<R>;
     using cfg = mid_cfg<R, B, TWO>;
-    constexpr int T = cfg::T, P1 = cfg::P1, P2 = cfg::P2, CPT = cfg::CPT, COLS = cfg::COLS;
+    constexpr int T = cfg::T, P1 = cfg::P1, P2 = cfg::P2, CPT = cfg::CPT;
     const int hi = TWO ? 0 : t / B, lo = TWO ? t : t % B;
     C u[32];
     if constexpr (!TWO) {
@@ -96,6 +99,11 @@ __device__ __forceinline__ void mid_passes(cpx<R> (&v)[32], R *plane, const cpx<
     }
     // ---- pass 2 over j2 (thread = (k1, j3) = (hi, lo)), twiddle W_L^{j3 k1} W_{32B}^{j3 k2}
     dft_n<R, INV, 32>(u);
+    if constexpr (TWO && B == 1) {                                  // one thread per 32-point line: done
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v[k] = u[brev(k, 5)];
+        return;
+    }
     {
         if constexpr (!TWO) {
             const C tw2_base = tw_full[hi * lo];
@@ -114,8 +122,8 @@ __device__ __forceinline__ void mid_passes(cpx<R> (&v)[32], R *plane, const cpx<
         }
         // ---- last exchange: row = column k' = k1 + 32 k2 (two-pass: k2), col = j3; thread t reads columns t + T i
         constexpr int CS = TWO ? 1 : 32;
-        R *wr = plane + (g * COLS + hi) * P2 + lo;
-        const R *rd = plane + (g * COLS + t) * P2;
+        R *wr = plane + g * cfg::LSTRIDE + hi * P2 + lo;
+        const R *rd = plane + g * cfg::LSTRIDE + t * P2;
 #pragma unroll
         for (int k2 = 0; k2 < 32; ++k2) wr[k2 * CS * P2] = u[brev(k2, 5)].x;
         lds_barrier();
@@ -441,6 +449,145 @@ void launch_filter_len(int L, const void *s, const void *H, void *y, long long n
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Complex lengths 32 .. 256 (B = 1, 2, 4, 8 threads per line, real lengths 64 .. 512).  Lines this short cannot be read
+// coalesced in the "thread t owns elements B j1 + t" pattern, so the group's contiguous block of lines is copied to LDS
+// first (flat, 8/16 B per lane) and picked up from there; results take the same way back, and the packed-real passes
+// work on the staged lines (one output bin per thread and step, both partners read from LDS).  Row pitch 33 B complex:
+// every LDS access of the kernel is conflict free.
+template<typename R> struct small_cfg { static constexpr int NT = sizeof(R) == 8 ? 128 : 256; };
+template<typename R, int B> constexpr size_t small_lds_bytes() { return ((size_t) (small_cfg<R>::NT / B) * 33 * B + 32 * B + 32 * B + 2) * 2 * sizeof(R); }
+
+template<typename R, int B, int MODE, bool INV>
+__global__ __launch_bounds__(small_cfg<R>::NT) void fft_small_kernel(const void *__restrict__ in, void *__restrict__ out, long long n_lines,
+                                                                     const cpx<R> *__restrict__ tw_full, const cpx<R> *__restrict__ tw_real,
+                                                                     R scale) {
+    using C = cpx<R>;
+    constexpr int NT = small_cfg<R>::NT, L = 32 * B, G = NT / B, P = 33 * B, LOGB = ilog2(B);
+    constexpr bool REAL_IN = MODE == DSC_MODE_R2C_CAST;
+    constexpr int IN_PITCH = MODE == DSC_MODE_C2R_PACKED ? L + 1 : L, OUT_PITCH = MODE == DSC_MODE_R2C_PACKED ? L + 1 : L;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    C *stage = (C *) lds_raw;
+    R *plane = (R *) lds_raw;                       // the exchange plane of mid_passes reuses the staging area
+    C *wtab = stage + G * P;                        // W_L^m, m < L
+    C *wreal = wtab + L;                            // W_2L^k, k <= L
+    const int tid = threadIdx.x;
+    const int g = tid / B, t = tid % B;
+    const long long line0 = (long long) blockIdx.x * G;
+    const long long left = n_lines - line0;
+    const int n_valid = left < G ? (int) left : G;
+
+    for (int i = tid; i < L; i += NT) wtab[i] = tw_full[i];
+    if constexpr (MODE == DSC_MODE_R2C_PACKED || MODE == DSC_MODE_C2R_PACKED)
+        for (int i = tid; i <= L; i += NT) wreal[i] = tw_real[i];
+    // ---- stage in: the group's block of lines, flat.  All loads are issued before the first LDS write; element
+    // e = tid + NT m of the block is (line, j) with e = line IN_PITCH + j, advanced incrementally (one division in all).
+    // Lines past the end of the batch read zeros (descriptor range).
+    constexpr int CB = (int) sizeof(C), EB = REAL_IN ? (int) sizeof(R) : CB;
+    constexpr int STEPS_IN = (G * IN_PITCH + NT - 1) / NT;                  // 32, or 33 for rows of L + 1 bins
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *) ((const char *) in + line0 * IN_PITCH * EB), 0,
+                                                                         n_valid * IN_PITCH * EB, 0x00020000);
+    {
+        C tmp[STEPS_IN];
+#pragma unroll
+        for (int m = 0; m < STEPS_IN; ++m) {
+            if constexpr (REAL_IN) tmp[m] = buf_load_real<kStream>(rin, tid * EB, m * NT * EB, R{});
+            else                   tmp[m] = buf_load<kCached>(rin, tid * EB, m * NT * EB, R{});
+        }
+        int line = tid / IN_PITCH, j = tid % IN_PITCH;
+#pragma unroll
+        for (int m = 0; m < STEPS_IN; ++m) {
+            if (m * NT + NT <= G * IN_PITCH || tid + m * NT < G * IN_PITCH) stage[line * P + j] = tmp[m];
+            j += NT % IN_PITCH;
+            line += NT / IN_PITCH;
+            if (j >= IN_PITCH) { j -= IN_PITCH; ++line; }
+        }
+    }
+    __syncthreads();
+    C v[32];
+    const C *mine = stage + g * P;
+    if constexpr (MODE == DSC_MODE_C2R_PACKED) {    // pre-pass (dsc_fft.h:194-228) for the thread's own bins k = B j1 + t
+#pragma unroll
+        for (int j1 = 0; j1 < 32; ++j1) {
+            const int k = B * j1 + t;
+            C a = mine[k], b = mine[L - k];
+            if (k == 0) { a.y = (R) 0; b.y = (R) 0; }
+            const C w = wreal[k];
+            const R wqx = (R) 0.5 * w.y, wqy = (R) 0.5 * w.x;
+            const R sx = a.x + b.x, sy = a.y - b.y, dx = a.x - b.x, dy = a.y + b.y;
+            v[j1] = C{(R) 0.5 * sx + (dx * wqx - dy * wqy), (R) 0.5 * sy + (dx * wqy + dy * wqx)};
+        }
+    } else {
+#pragma unroll
+        for (int j1 = 0; j1 < 32; ++j1) v[j1] = mine[B * j1 + t];
+    }
+    __syncthreads();                                // staged lines consumed: the area becomes the exchange plane
+
+    mid_passes<R, B, true, INV>(v, plane, wtab, tw_full, g, t, tid);
+
+    // ---- results back to the staging area in natural order: v[i B + p] = bin (t + B i) + 32 brev(p)
+    C *mine_w = stage + g * P;
+    const R sc = MODE == DSC_MODE_R2C_PACKED ? (R) 1 : scale;
+#pragma unroll
+    for (int i = 0; i < 32 / B; ++i)
+#pragma unroll
+        for (int p = 0; p < B; ++p) {
+            const C r = v[i * B + p];
+            mine_w[(t + B * i) + 32 * brev(p, LOGB)] = C{r.x * sc, r.y * sc};
+        }
+    __syncthreads();
+    // ---- stage out, flat (stores past the end of the batch are dropped by the descriptor range)
+    constexpr int STEPS_OUT = (G * OUT_PITCH + NT - 1) / NT;
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *) ((char *) out + line0 * OUT_PITCH * CB), 0,
+                                                                          n_valid * OUT_PITCH * CB, 0x00020000);
+    int line = tid / OUT_PITCH, k = tid % OUT_PITCH;
+#pragma unroll
+    for (int m = 0; m < STEPS_OUT; ++m) {
+        const bool inside = m * NT + NT <= G * OUT_PITCH || tid + m * NT < G * OUT_PITCH;
+        C x;
+        if constexpr (MODE == DSC_MODE_R2C_PACKED) {                      // dsc_fft.h:199-225, one bin per thread and step
+            const C *row = stage + (inside ? line : 0) * P;
+            const C a = row[k == L ? 0 : k], b = row[k == 0 || k == L ? 0 : L - k];
+            const C w = wreal[k];
+            const R wqx = (R) 0.5 * w.y, wqy = (R) -0.5 * w.x;
+            const R sx = a.x + b.x, sy = a.y - b.y, dx = a.x - b.x, dy = a.y + b.y;
+            x = C{((R) 0.5 * sx + (dx * wqx - dy * wqy)) * scale, ((R) 0.5 * sy + (dx * wqy + dy * wqx)) * scale};
+            if (k == 0 || k == L) x.y = (R) 0;
+        } else {
+            x = stage[(inside ? line : 0) * P + k];
+        }
+        buf_store<kCached>(x, rout, inside ? tid * CB : 0x7f000000, m * NT * CB);
+        k += NT % OUT_PITCH;
+        line += NT / OUT_PITCH;
+        if (k >= OUT_PITCH) { k -= OUT_PITCH; ++line; }
+    }
+}
+
+template<typename R, int B, int MODE, bool INV>
+void launch_small_one(const void *in, void *out, long long n_lines, const void *tw_full, const void *tw_real, double scale, hipStream_t stream) {
+    constexpr int G = small_cfg<R>::NT / B;
+    constexpr size_t lds = small_lds_bytes<R, B>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void) hipFuncSetAttribute((const void *) fft_small_kernel<R, B, MODE, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        attr_set = true;
+    }
+    const long long groups = (n_lines + G - 1) / G;
+    hipLaunchKernelGGL((fft_small_kernel<R, B, MODE, INV>), dim3((unsigned) groups), dim3(small_cfg<R>::NT), lds, stream, in, out, n_lines,
+                       (const cpx<R> *) tw_full, (const cpx<R> *) tw_real, (R) scale);
+}
+
+template<typename R, int B>
+void launch_small(const void *in, void *out, long long n_lines, dsc_fft_mode mode, bool inverse, const void *tw_full, const void *tw_real,
+                  double scale, hipStream_t stream) {
+    if (mode == DSC_MODE_R2C_PACKED)      launch_small_one<R, B, DSC_MODE_R2C_PACKED, false>(in, out, n_lines, tw_full, tw_real, scale, stream);
+    else if (mode == DSC_MODE_C2R_PACKED) launch_small_one<R, B, DSC_MODE_C2R_PACKED, true>(in, out, n_lines, tw_full, tw_real, scale, stream);
+    else if (mode == DSC_MODE_R2C_CAST && !inverse) launch_small_one<R, B, DSC_MODE_R2C_CAST, false>(in, out, n_lines, tw_full, tw_real, scale, stream);
+    else if (mode == DSC_MODE_R2C_CAST)   launch_small_one<R, B, DSC_MODE_R2C_CAST, true>(in, out, n_lines, tw_full, tw_real, scale, stream);
+    else if (inverse)                     launch_small_one<R, B, DSC_MODE_C2C, true>(in, out, n_lines, tw_full, tw_real, scale, stream);
+    else                                  launch_small_one<R, B, DSC_MODE_C2C, false>(in, out, n_lines, tw_full, tw_real, scale, stream);
+}
+
 template<typename R, int B, bool TWO, int MODE, bool INV, bool PAD>
 void launch_pad(const void *in, void *out, long long n_lines, const void *tw_full, const void *tw_real, double scale, int in_pitch_b,
                 int in_len_b, hipStream_t stream) {
@@ -477,6 +624,9 @@ void launch_b(const void *in, void *out, long long n_lines, dsc_fft_mode mode, b
 
 }  // namespace
 
+// lengths 32 .. 256: full contiguous lines only (zero-padded / cropped lines of 256 take the PAD instantiation of fft_mid_kernel)
+bool dsc_fft_regs_small_supports(int L) { return L == 32 || L == 64 || L == 128 || L == 256; }   // measured: at 512 the direct-load kernel wins
+
 bool dsc_fft_regs_mid_supports(int L, dsc_fft_mode mode, bool single_precision) {
     if (L == 32768) return single_precision && mode == DSC_MODE_C2C;   // the packed-real 65536-point f32 transforms have their own kernels
     return L == 256 || L == 512 || L == 1024 || L == 2048 || L == 4096 || L == 8192 || L == 16384;
@@ -501,6 +651,20 @@ static void launch_len(const void *in, void *out, long long n_lines, int L, dsc_
 void dsc_launch_fft_regs_mid(const void *in, void *out, long long n_lines, int L, dsc_fft_mode mode, bool inverse, bool single_precision,
                              const void *tw_full, const void *tw_real, double scale, long long in_pitch, int in_len, hipStream_t stream) {
     if (n_lines <= 0) return;
+    if (in_pitch < 0 && dsc_fft_regs_small_supports(L)) {       // full lines of 32 .. 256 points: the LDS-staged kernel
+        if (single_precision) {
+            if (L == 32)       launch_small<float, 1>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream);
+            else if (L == 64)  launch_small<float, 2>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream);
+            else if (L == 128) launch_small<float, 4>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream);
+            else               launch_small<float, 8>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream);
+        } else {
+            if (L == 32)       launch_small<double, 1>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream);
+            else if (L == 64)  launch_small<double, 2>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream);
+            else if (L == 128) launch_small<double, 4>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream);
+            else               launch_small<double, 8>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream);
+        }
+        return;
+    }
     const int real_b = single_precision ? 4 : 8;
     const int elem_b = (mode == DSC_MODE_R2C_PACKED || mode == DSC_MODE_R2C_CAST) ? real_b : 2 * real_b;
     const int pb = in_pitch < 0 ? -1 : (int) (in_pitch * elem_b), lb = in_pitch < 0 ? 0 : in_len * elem_b;

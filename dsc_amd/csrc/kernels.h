@@ -90,6 +90,7 @@ void   dsc_launch_rfft_two_pass(const void *in, void *out, long long rows, int L
 // (fft_regs_mid.hip).  in / out: [n_lines][L] complex (C2C), [n_lines][2L] reals -> [n_lines][L+1] bins
 // (R2C_PACKED) or the converse (C2R_PACKED).  tw_full: W_L^k, k < L; tw_real: W_{2L}^k, k <= L.
 bool dsc_fft_regs_mid_supports(int L, dsc_fft_mode mode, bool single_precision);
+bool dsc_fft_regs_small_supports(int L);        // 32 .. 256: same launcher, full contiguous lines only (in_pitch < 0)
 // in_pitch / in_len: input line pitch and valid length in input elements (reals for R2C_PACKED / R2C_CAST, complex otherwise):
 // shorter lines are zero padded, longer ones cropped; in_pitch < 0 = full contiguous lines (the fast instantiation).
 void dsc_launch_fft_regs_mid(const void *in, void *out, long long n_lines, int L, dsc_fft_mode mode, bool inverse, bool single_precision,

@@ -200,7 +200,7 @@ def test_f64_262144_register_path(dsc):
         assert rel_l2(bh, x) <= 1e-14
 
 
-@pytest.mark.parametrize('n', [512, 1024, 2048, 4096, 8192, 16384, 32768])
+@pytest.mark.parametrize('n', [1024, 2048, 4096, 8192, 16384, 32768])
 def test_mid_size_register_path(dsc, n):
     """Real lengths 512 .. 32768 (complex 256 .. 16384) of contiguous full rows run in
     fft_regs_mid.hip; row counts that are not a multiple of the lines-per-workgroup exercise
@@ -246,7 +246,7 @@ def test_mid_size_register_path(dsc, n):
         assert_close(Fi.numpy()[0], port.ifft(xr[0]), what=f'ifft(real) n={n // 2}')
 
 
-@pytest.mark.parametrize('n', [512, 1024, 2048, 4096, 8192, 16384, 32768])
+@pytest.mark.parametrize('n', [1024, 2048, 4096, 8192, 16384, 32768])
 def test_mid_size_register_path_f64(dsc, n):
     """The same kernels in f64 (tolerance 1e-12 against the oracle)."""
     from oracle import port
@@ -575,3 +575,38 @@ def test_rccl_sees_arena_memory_one_rank():
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_rccl_view.py')], capture_output=True, text=True, timeout=300,
                        cwd=root, env=env)
     assert r.returncode == 0 and 'OK' in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize('dt', [np.float32, np.float64])
+@pytest.mark.parametrize('n', [64, 128, 256, 512])
+def test_small_size_register_path(dsc, dt, n):
+    """Real lengths 64 .. 512 (complex 32 .. 256): the LDS-staged register kernel of fft_regs_mid.hip; all transforms, row
+    counts that leave the last workgroup partially filled, against the oracle."""
+    from oracle import port
+    cdt = np.complex64 if dt == np.float32 else np.complex128
+    rng = np.random.default_rng(n + 3)
+    tol = 1e-6 if dt == np.float32 else 1e-14
+    for rows in (1, 7, 300, 1031):
+        x = rng.standard_normal((rows, n)).astype(dt)
+        X = dsc.rfft(dsc.from_numpy(x))
+        assert dsc.last_fft_path() == 'regs_small'
+        got = X.numpy()
+        for r in sorted({0, rows // 2, rows - 1}):
+            assert_close(got[r], port.rfft(x[r]), what=f'rfft n={n} row {r}/{rows}')
+        assert rel_l2(got, np.fft.rfft(x.astype(np.float64), axis=-1)) <= tol
+        assert np.all(got[:, 0].imag == 0) and np.all(got[:, -1].imag == 0)
+        Xq = got.copy()
+        Xq[:, 0] += 2j
+        Xq[:, -1] -= 3j
+        back = dsc.irfft(dsc.from_numpy(Xq))
+        assert dsc.last_fft_path() == 'regs_small'
+        assert_close(back.numpy()[rows - 1], port.irfft(Xq[rows - 1]), what=f'irfft n={n}')
+        assert rel_l2(back.numpy(), x) <= tol
+        z = (rng.standard_normal((rows, n // 2)) + 1j * rng.standard_normal((rows, n // 2))).astype(cdt)
+        Z = dsc.fft(dsc.from_numpy(z))
+        assert dsc.last_fft_path() == 'regs_small'
+        assert_close(Z.numpy()[rows - 1], port.fft(z[rows - 1]), what=f'fft n={n // 2}')
+        assert rel_l2(dsc.ifft(Z).numpy(), z) <= tol
+        xr = x[:, :n // 2].copy()
+        assert_close(dsc.fft(dsc.from_numpy(xr)).numpy()[0], port.fft(xr[0]), what=f'fft(real) n={n // 2}')
+        assert_close(dsc.ifft(dsc.from_numpy(xr)).numpy()[rows - 1], port.ifft(xr[rows - 1]), what=f'ifft(real) n={n // 2}')
