@@ -1,56 +1,63 @@
-"""`dsc.profile()` — mirror of python/dsc/profiler.py:14-63 on top of dsc_traces_record / dsc_dump_traces /
-dsc_clear_traces.  The dump holds two tracks: the operator calls on the host and the spans their kernels took on the
-HIP stream.  Serving the file to ui.perfetto.dev (what the reference's stop_recording always does, blocking until the
-browser has fetched it) is opt-in here: `profile('traces.json', serve=True)`."""
-import socketserver
-from contextlib import contextmanager
-from http.server import SimpleHTTPRequestHandler
+"""`dsc.profile()` on top of dsc_traces_record / dsc_dump_traces / dsc_clear_traces (reference: python/dsc/profiler.py).
+
+The dump is a Perfetto / chrome://tracing JSON file with two tracks: the operator calls on the host and the spans their
+kernels took on the HIP stream.  The reference's stop_recording always starts a local web server and blocks until
+ui.perfetto.dev has fetched the file; here the file is simply written (drag it into https://ui.perfetto.dev), and
+`perfetto_url()` offers the served variant for interactive sessions."""
+import contextlib
+import functools
+import http.server
+import os
+import threading
 
 from . import _bindings as B
 from .context import _get_ctx
 
 
-def start_recording():
+def start_recording() -> None:
     B.dsc_traces_record(_get_ctx(), True)
 
 
-class _PerfettoServer(SimpleHTTPRequestHandler):
-    def log_message(self, format, *args):     # noqa: A002
-        pass
-
-    def end_headers(self):
-        self.send_header('Access-Control-Allow-Origin', '*')
-        return super().end_headers()
-
-    def do_GET(self):
-        self.server.last_request = self.path
-        return super().do_GET()
-
-    def do_POST(self):
-        self.send_error(404, 'File not found')
-
-
-def _serve_traces(traces_file: str, port: int = 9001):
-    socketserver.TCPServer.allow_reuse_address = True
-    with socketserver.TCPServer(('127.0.0.1', port), _PerfettoServer) as httpd:
-        print(f'Open URL in browser: https://ui.perfetto.dev/#!/?url=http://127.0.0.1:{port}/{traces_file}')
-        while httpd.__dict__.get('last_request') != '/' + traces_file:
-            httpd.handle_request()
-
-
-def stop_recording(traces_file: str, clear: bool = True, serve: bool = False):
-    B.dsc_traces_record(_get_ctx(), False)
-    B.dsc_dump_traces(_get_ctx(), traces_file.encode())
-    if serve:
-        _serve_traces(traces_file)
+def stop_recording(traces_file: str, clear: bool = True) -> str:
+    ctx = _get_ctx()
+    B.dsc_traces_record(ctx, False)
+    B.dsc_dump_traces(ctx, os.fsencode(traces_file))
     if clear:
-        B.dsc_clear_traces(_get_ctx())
+        B.dsc_clear_traces(ctx)
+    return traces_file
 
 
-@contextmanager
-def profile(dump_file: str = 'traces.json', serve: bool = False):
+@contextlib.contextmanager
+def profile(dump_file: str = 'traces.json'):
+    """with dsc.profile('run.json'): ...   — records every operator call inside the block."""
     start_recording()
     try:
-        yield
+        yield dump_file
     finally:
-        stop_recording(dump_file, True, serve)
+        stop_recording(dump_file, clear=True)
+
+
+def perfetto_url(traces_file: str, port: int = 9001, one_shot: bool = True) -> str:
+    """Serve `traces_file` on 127.0.0.1 for ui.perfetto.dev (CORS header set) from a daemon thread and return the URL to
+    open.  With one_shot the server stops after the file has been fetched once."""
+    directory, name = os.path.split(os.path.abspath(traces_file))
+
+    class Handler(http.server.SimpleHTTPRequestHandler):
+        def end_headers(self):
+            self.send_header('Access-Control-Allow-Origin', 'https://ui.perfetto.dev')
+            super().end_headers()
+
+        def log_message(self, *args):
+            pass
+
+    server = http.server.ThreadingHTTPServer(('127.0.0.1', port), functools.partial(Handler, directory=directory))
+
+    def run():
+        if one_shot:
+            server.handle_request()
+            server.server_close()
+        else:
+            server.serve_forever()
+
+    threading.Thread(target=run, daemon=True).start()
+    return f'https://ui.perfetto.dev/#!/?url=http://127.0.0.1:{port}/{name}'
