@@ -571,7 +571,11 @@ def test_rccl_sees_arena_memory_one_rank():
     import subprocess
     import sys
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29613')
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        free_port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port))
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_rccl_view.py')], capture_output=True, text=True, timeout=300,
                        cwd=root, env=env)
     assert r.returncode == 0 and 'OK' in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
