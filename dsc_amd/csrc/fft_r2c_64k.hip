@@ -425,63 +425,49 @@ __global__ __launch_bounds__(1024) void rfft64k_kernel(const float *__restrict__
     }
 }
 
-// Inverse packed-real pre-pass in the mirrored lane layout: on entry v[a] = Y[c + 1024 a]
-// (natural row order), on exit v[a] = Z[c + 1024 a] / M.  y_last = bin M (column 0 only).
-__device__ __forceinline__ void inverse_prepass(cf (&v)[32], cf y_last, const f2 *aux, int wave_sgpr) {
+// Inverse packed-real pre-pass with the partner bins LOADED by the lane itself: on entry v[a] = Y[k], v[16 + a] = Y[M - k] for
+// the lane's first 16 rows, k = c + 1024 a (Y[M - k] is row 31 - a of the partner column 1024 - c: the same 32 loads per
+// lane as reading one's own 32 rows, but the pair is complete without a ds_bpermute).  Each pair gives Z[k] — this lane's
+// row a — and Z[M - k] — the PARTNER's row 31 - a, which is the only thing exchanged (32 ds_bpermute instead of 64).
+// On exit v[r] = Z[c + 1024 r] / M in natural row order.  y_mid = bin M/2 (column 0 only).
+__device__ __forceinline__ void inverse_prepass_direct(cf (&v)[32], cf y_mid, const f2 *aux, int wave_sgpr) {
     constexpr float kScale = 1.0f / (float) kM;            // 2/(2n), dsc_fft.h:232
     const int t1 = thread_id(wave_sgpr);
     const int lane = t1 & 63, wave = t1 >> 6;
     const int c = column_of(wave, lane);
     const int partner_addr = partner_byte_addr(wave, lane);
-    // Column 0 pairs row a with row 32 - a of itself and row 0 with bin M.  Shifting its rows
-    // 17..31 down by one (bin M into row 31) turns that into the general "row a with row 31 - a
-    // of the partner" with itself as partner.
-    // The shift is done in two parts, each right before the batch that needs it: batch 0 (rows 0..7 with 31..24)
-    // then depends only on rows 0..7, 24..31 and bin M — the loads the pipeline issues FIRST — and starts while
-    // rows 8..23 are still in flight.
-    const cf y_mid = v[16];                                // bin M/2 pairs with itself
-    const cf row24 = v[24];
-    if (wave == 0) {
-#pragma unroll
-        for (int r = 24; r < 31; ++r) v[r] = lane == 0 ? v[r + 1] : v[r];
-        v[31] = lane == 0 ? y_last : v[31];
-        if (lane == 0) { v[0].y = 0.f; v[31].y = 0.f; }    // dsc_fft.h:227-228 reads the real parts only
-    }
+    if (wave == 0 && lane == 0) { v[0].y = 0.f; v[16].y = 0.f; }          // bins 0 and M: real parts only (dsc_fft.h:227-228)
     const cf wpre = to_cf(aux[kAuxW65536 + c]);
     const cf wq_base = cf{0.5f * kScale * wpre.y, 0.5f * kScale * wpre.x};      // (i/2) conj(W^c) / M
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {                 // two batches of 8 pairs: VGPR budget
-        if (half == 1 && wave == 0) {                      // second part of the column-0 shift: rows 16..23
-#pragma unroll
-            for (int r = 16; r < 23; ++r) v[r] = lane == 0 ? v[r + 1] : v[r];
-            v[23] = lane == 0 ? row24 : v[23];
-        }
-        cf q[8], zm[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int a = half * 8 + i;
-            q[i].x = bperm(partner_addr, v[31 - a].x);
-            q[i].y = bperm(partner_addr, v[31 - a].y);
-        }
+    for (int half = 0; half < 2; ++half) {                 // two batches of 8 pairs: VGPR budget, and batch 0 only needs the
+        cf zm[8];                                          // loads the pipeline issues first
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int a = half * 8 + i;
             const cf cj = cf{root64_re(a), -root64_im(a)}; // conj(W_64^a)
             const cf wq = a == 0 ? wq_base : cmul(wq_base, cj);
-            real_pair(v[a], q[i], wq, 0.5f * kScale, v[a], zm[i]);
+            real_pair(v[a], v[16 + a], wq, 0.5f * kScale, v[a], zm[i]);
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {                      // the partner finished my rows 31..16
+        for (int i = 0; i < 8; ++i) {                      // the partner's Z[M - k] of its pair a is my row 31 - a
             const int a = half * 8 + i;
-            v[31 - a].x = bperm(partner_addr, zm[i].x);
-            v[31 - a].y = bperm(partner_addr, zm[i].y);
+            v[16 + a].x = bperm(partner_addr, zm[i].x);
+            v[16 + a].y = bperm(partner_addr, zm[i].y);
         }
     }
-    if (wave == 0) {                                       // undo the shift of column 0
+    cf w[32];
 #pragma unroll
-        for (int r = 31; r > 16; --r) v[r] = lane == 0 ? v[r - 1] : v[r];
-        v[16] = lane == 0 ? cf{kScale * y_mid.x, -kScale * y_mid.y} : v[16];   // Z[M/2] = conj Y[M/2] (dsc_fft.h:218)
+    for (int r = 0; r < 16; ++r) { w[r] = v[r]; w[16 + r] = v[31 - r]; }  // v[16 + a] holds row 31 - a
+    if (wave == 0) {
+        // Column 0 pairs row a with row 32 - a of ITSELF (and row 0 with bin M): what came back as "row 31 - a" is row
+        // 32 - a.  Shift up by one; row 16 = bin M/2 pairs with itself: Z[M/2] = conj Y[M/2] (dsc_fft.h:218).
+#pragma unroll
+        for (int r = 31; r > 16; --r) w[r] = lane == 0 ? w[r - 1] : w[r];
+        w[16] = lane == 0 ? cf{kScale * y_mid.x, -kScale * y_mid.y} : w[16];
     }
+#pragma unroll
+    for (int r = 0; r < 32; ++r) v[r] = w[r];
 }
 
 // Tail shared by the inverse and the fused kernels: v[p] = z[t + 1024 br5(p)] (time samples of
@@ -533,22 +519,11 @@ __device__ __forceinline__ void unzip_rows(cf (&v)[32]) {
     for (int a = 0; a < 32; ++a) v[a] = nxt[a];
 }
 
-// The inverse kernel's pipelined loads: even registers 0..14 = rows 0..7, even 16..30 = rows 24..31, odd = rows 8..23
-__device__ __forceinline__ void unzip_rows_outer_first(cf (&v)[32]) {
-    cf nxt[32];
-#pragma unroll
-    for (int a = 0; a < 8; ++a) { nxt[a] = v[2 * a]; nxt[24 + a] = v[16 + 2 * a]; }
-#pragma unroll
-    for (int a = 8; a < 24; ++a) nxt[a] = v[2 * (a - 8) + 1];
-#pragma unroll
-    for (int a = 0; a < 32; ++a) v[a] = nxt[a];
-}
-
 // ------------------------------------------------------------------------------------------
 // inverse: X [batch][32769] c32  ->  x [batch][65536] f32        (dsc_irfft, dsc_fft.h:194-236)
 //
-// The forward pipeline run backwards.  The bins are read in the column layout of the forward
-// post-pass, the packed-real pre-pass pairs them through ds_bpermute, and three
+// The forward pipeline run backwards.  Each lane reads its column's first 16 rows AND their pairing partners (rows 31..16
+// of the mirror column), the packed-real pre-pass completes the pairs and exchanges only the results through ds_bpermute, and three
 // conjugate-twiddle passes end with thread t holding z[t + 1024 r]: the time samples leave as
 // aligned, coalesced 8-B stores.  The 2/(2n) scale is folded into the pre-pass constants.
 // in_pitch: bins between input rows; in_len <= 32769 bins per row are used, missing ones read as zero (dsc.cpp:2149-2157)
@@ -567,17 +542,22 @@ __global__ __launch_bounds__(1024) void irfft64k_kernel(const f2 *__restrict__ X
     // as the staging writes have freed the registers, ahead of this row's stores.
     // Loads keep the default cache policy: spectrum rows are skewed by 8 B x row, so neighbouring
     // waves share their boundary lines (nt loads measured 5 % slower on this kernel).
+    // Register convention at the top of a row: v[a] = Y[c + 1024 a], v[16 + a] = Y[M - c - 1024 a] (a < 16): see inverse_prepass_direct.
     cf v[32];
-    cf y_last = cf{0.f, 0.f};
+    cf y_mid = cf{0.f, 0.f};
     {
         const int row0 = blockIdx.x;
         const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(
             (void *) (X + (size_t) row0 * in_pitch), 0, row0 < batch ? in_len * 8 * IO_ON : 0, 0x00020000);
         const int t0 = thread_id(wave_sgpr);
         const int c = column_of(t0 >> 6, t0 & 63);
+        const int pv = (kM - c - 15 * 1024) * 8;                                     // Y[M - c - 1024 a] = pv + (15 - a) * 8192
 #pragma unroll
-        for (int a = 0; a < 32; ++a) v[a] = load_c_cached(r0, c * 8, a * 8192);     // Y[c + 1024 a]
-        if (c == 0) y_last = load_c_cached(r0, kM * 8, 0);                          // bin M
+        for (int a = 0; a < 16; ++a) {
+            v[a] = load_c_cached(r0, c * 8, a * 8192);
+            v[16 + a] = load_c_cached(r0, pv, (15 - a) * 8192);
+        }
+        if (c == 0) y_mid = load_c_cached(r0, (kM / 2) * 8, 0);
     }
 
     for (int row = blockIdx.x; row < batch; row += gridDim.x) {
@@ -587,26 +567,42 @@ __global__ __launch_bounds__(1024) void irfft64k_kernel(const f2 *__restrict__ X
         const __amdgpu_buffer_rsrc_t rout =
             __builtin_amdgcn_make_buffer_rsrc((void *) (x + (size_t) row * 65536), 0, 65536 * 4 * IO_ON, 0x00020000);
 
-        inverse_prepass(v, y_last, aux, wave_sgpr);
+        inverse_prepass_direct(v, y_mid, aux, wave_sgpr);
         three_passes<true>(v, plane, w1024, aux, wave_sgpr, true, false);      // v[p] = z[t + 1024 br5(p)]
 
         const int t4 = thread_id(wave_sgpr);
         const int c = column_of(t4 >> 6, t4 & 63);
+        const int pv = (kM - c - 15 * 1024) * 8;
         staged_time_store(v, plane, rout, wave_sgpr, [&](bool first_half) {
-            // consumption order of the pre-pass: bin M and rows 0..7, 24..31 first (even registers), rows 8..23 second (odd)
+            // consumption order of the pre-pass: pairs 0..7 (and bin M/2) into the even registers, pairs 8..15 into the odd ones
             if (first_half) {
-                y_last = cf{0.f, 0.f};
-                if (c == 0) y_last = load_c_cached(rnext, kM * 8, 0);
+                y_mid = cf{0.f, 0.f};
+                if (c == 0) y_mid = load_c_cached(rnext, (kM / 2) * 8, 0);
 #pragma unroll
-                for (int a = 0; a < 8; ++a) v[2 * a] = load_c_cached(rnext, c * 8, a * 8192);                // rows 0..7
-#pragma unroll
-                for (int a = 24; a < 32; ++a) v[2 * (a - 16)] = load_c_cached(rnext, c * 8, a * 8192);       // rows 24..31
+                for (int a = 0; a < 8; ++a) {
+                    v[2 * a] = load_c_cached(rnext, c * 8, a * 8192);
+                    v[16 + 2 * a] = load_c_cached(rnext, pv, (15 - a) * 8192);
+                }
             } else {
 #pragma unroll
-                for (int a = 8; a < 24; ++a) v[2 * (a - 8) + 1] = load_c_cached(rnext, c * 8, a * 8192);     // rows 8..23
+                for (int a = 8; a < 16; ++a) {
+                    v[2 * (a - 8) + 1] = load_c_cached(rnext, c * 8, a * 8192);
+                    v[17 + 2 * (a - 8)] = load_c_cached(rnext, pv, (15 - a) * 8192);
+                }
             }
         });
-        unzip_rows_outer_first(v);
+        {   // back to the convention above (a renaming, every index is a constant)
+            cf nxt[32];
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                nxt[a] = v[2 * a];
+                nxt[16 + a] = v[16 + 2 * a];
+                nxt[8 + a] = v[2 * a + 1];
+                nxt[24 + a] = v[17 + 2 * a];
+            }
+#pragma unroll
+            for (int a = 0; a < 32; ++a) v[a] = nxt[a];
+        }
     }
 }
 
