@@ -91,7 +91,7 @@ extern "C" dsc_fft_plan *dsc_plan_fft(dsc_ctx *ctx, int n, dsc_fft_type fft_type
     }
 
     const size_t real_sz = twd == DSC_F32 ? 4 : 8;
-    const bool regs64k = fft_type == DSC_FFT_REAL && twd == DSC_F32 && fft_n == 32768;
+    const bool regs64k = twd == DSC_F32 && fft_n == 32768;          // the 65536-point real and the 32768-point complex register kernels
     const size_t full_bytes = DSC_ALIGN_UP((size_t) fft_n * 2 * real_sz, DSC_DEVICE_ALIGN);
     const size_t real_bytes = fft_type == DSC_FFT_REAL ? DSC_ALIGN_UP(((size_t) fft_n + 1) * 2 * real_sz, DSC_DEVICE_ALIGN) : 0;
     const size_t aux_bytes = regs64k ? DSC_ALIGN_UP(dsc_r2c64k_table_bytes(), DSC_DEVICE_ALIGN) : 0;
@@ -273,6 +273,13 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
         }
     }
 
+    // register-resident 32768-point complex transform (c32 rows)
+    if (sp && j.mode == DSC_MODE_C2C && j.L == 32768 && inner == 1 && plan->tw_aux != nullptr) {
+        dsc_launch_fft32k_c32(j.x->data, j.out->data, (int) n_lines, j.x->shape[j.slot], j.in_len, j.inverse, plan->tw_aux, ctx->n_cu,
+                              ctx->stream);
+        ctx->last_fft_path = "c2c_32k_regs";
+        return;
+    }
     // register-resident 65536-point real transforms: contiguous full rows only
     if (sp && packed && j.L == 32768 && inner == 1 && plan->tw_aux != nullptr) {
         if (j.mode == DSC_MODE_R2C_PACKED) {               // any row length: shorter rows are zero padded, longer ones cropped

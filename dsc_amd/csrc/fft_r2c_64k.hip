@@ -299,6 +299,7 @@ __device__ __forceinline__ int partner_byte_addr(int wave, int lane) {
     return ((wave == 0 && (lane == 63 || lane == 0)) ? lane : 63 - lane) * 4;
 }
 
+#ifndef DSC_R2C64K_HELPERS_ONLY       // fft_c2c_32k.hip includes this file for the building blocks only
 // ------------------------------------------------------------------------------------------
 // forward: x [batch][65536] f32  ->  X [batch][32769] c32
 // in_pitch: floats between input rows; in_len <= 65536: valid samples per row — the rest of the transform length reads
@@ -425,6 +426,8 @@ __global__ __launch_bounds__(1024) void rfft64k_kernel(const float *__restrict__
     }
 }
 
+#endif  // DSC_R2C64K_HELPERS_ONLY
+
 // Inverse packed-real pre-pass with the partner bins LOADED by the lane itself: on entry v[a] = Y[k], v[16 + a] = Y[M - k] for
 // the lane's first 16 rows, k = c + 1024 a (Y[M - k] is row 31 - a of the partner column 1024 - c: the same 32 loads per
 // lane as reading one's own 32 rows, but the pair is complete without a ds_bpermute).  Each pair gives Z[k] — this lane's
@@ -519,6 +522,7 @@ __device__ __forceinline__ void unzip_rows(cf (&v)[32]) {
     for (int a = 0; a < 32; ++a) v[a] = nxt[a];
 }
 
+#ifndef DSC_R2C64K_HELPERS_ONLY       // fft_c2c_32k.hip includes this file for the building blocks only
 // ------------------------------------------------------------------------------------------
 // inverse: X [batch][32769] c32  ->  x [batch][65536] f32        (dsc_irfft, dsc_fft.h:194-236)
 //
@@ -729,8 +733,11 @@ __global__ __launch_bounds__(1024) void filter64k_kernel(const float *__restrict
     }
 }
 
+#endif  // DSC_R2C64K_HELPERS_ONLY
+
 }  // namespace
 
+#ifndef DSC_R2C64K_HELPERS_ONLY
 size_t dsc_r2c64k_table_bytes() { return (size_t) kAuxEntries * sizeof(float) * 2; }
 
 void dsc_r2c64k_build_tables(void *host_dst) {
@@ -784,3 +791,4 @@ void dsc_launch_filter64k(const float *s, const void *H, float *y, int batch, in
     const int grid = batch < n_cu ? batch : n_cu;
     hipLaunchKernelGGL(filter64k_kernel, dim3(grid), dim3(1024), kLdsBytes, stream, s, (const f2 *) H, y, batch, (const f2 *) aux, in_pitch, in_len);
 }
+#endif  // DSC_R2C64K_HELPERS_ONLY

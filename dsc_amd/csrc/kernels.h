@@ -70,6 +70,9 @@ void   dsc_r2c64k_build_tables(void *host_dst);          // fills a host staging
 // in_pitch: floats between input rows; in_len <= 65536 valid samples per row, the rest reads as zero (zero padding / crop)
 void   dsc_launch_rfft64k(const float *x, void *X, int batch, int in_pitch, int in_len, const void *aux, int n_cu, hipStream_t stream);
 void   dsc_launch_irfft64k(const void *X, float *x, int batch, int in_pitch, int in_len, const void *aux, int n_cu, hipStream_t stream);   // pitch / valid length in bins
+// complex 32768-point transform of c32 rows in the same design (z: [batch][in_pitch], in_len <= 32768 samples used)
+void   dsc_launch_fft32k_c32(const void *z, void *Z, int batch, int in_pitch, int in_len, bool inverse, const void *aux, int n_cu,
+                             hipStream_t stream);
 // y = irfft(rfft(s) * H) fused; H: [32769] c32
 void   dsc_launch_filter64k(const float *s, const void *H, float *y, int batch, int in_pitch, int in_len, const void *aux, int n_cu,
                             hipStream_t stream);

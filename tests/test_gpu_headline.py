@@ -614,3 +614,25 @@ def test_small_size_register_path(dsc, dt, n):
         xr = x[:, :n // 2].copy()
         assert_close(dsc.fft(dsc.from_numpy(xr)).numpy()[0], port.fft(xr[0]), what=f'fft(real) n={n // 2}')
         assert_close(dsc.ifft(dsc.from_numpy(xr)).numpy()[rows - 1], port.ifft(xr[rows - 1]), what=f'ifft(real) n={n // 2}')
+
+
+def test_complex_32768_register_path(dsc):
+    """dsc_fft / dsc_ifft of c32 rows of 32768 samples: the persistent register kernel of fft_c2c_32k.hip (full and
+    zero-padded rows, ragged batch sizes)."""
+    from oracle import port
+    rng = np.random.default_rng(321)
+    L = 32768
+    for rows, ls in ((1, L), (3, L), (300, L), (2, L - 9), (2, L + 4)):
+        z = (rng.standard_normal((rows, ls)) + 1j * rng.standard_normal((rows, ls))).astype(np.complex64)
+        Z = dsc.fft(dsc.from_numpy(z), n=L)
+        assert dsc.last_fft_path() == 'c2c_32k_regs'
+        zh = Z.numpy()
+        for r in sorted({0, rows - 1}):
+            assert_close(zh[r], port.fft(z[r], L), what=f'fft 32768 ls={ls} row {r}')
+        zp = np.zeros((rows, L), np.complex128)
+        zp[:, :min(ls, L)] = z[:, :L]
+        assert rel_l2(zh, np.fft.fft(zp, axis=-1)) <= 1e-6
+        back = dsc.ifft(Z)
+        assert dsc.last_fft_path() == 'c2c_32k_regs'
+        assert_close(back.numpy()[rows - 1], port.ifft(zh[rows - 1]), what='ifft 32768')
+        assert rel_l2(back.numpy(), zp) <= 1e-6
