@@ -93,6 +93,113 @@ def cpu_baseline(rows=1024, reps=5, warm=2):
     }
 
 
+def gather_phase(args, dist, world, rank, rows, barrier_sync, gpu):
+    """Put the P output shards next to each other on every rank (dsc_amd/shard.py) with each requested method, timed
+    (a) pipelined with the transforms — chunk i travels while chunk i+1 is computed — and (b) on its own, and PROVEN:
+    every slot of the persistent [P x shard] destination is checked against its owner's checksum and sample rows.
+    Backend-agnostic: RCCL on device buffers; gloo on host buffers (CPU dry run, or host staging when --share-device
+    rehearses N > 1 on one GPU); 'ipc' (direct pushes over HIP IPC) whenever there is a GPU."""
+    import numpy as np
+    import torch
+    from dsc_amd import shard
+    methods = [m for m in args.gather_methods.split(',') if m]
+    bins = N_FFT // 2 + 1
+    on_device = gpu is not None and args.backend == 'nccl'
+    if gpu is None:
+        # CPU dry run: small deterministic per-rank shards, same control flow
+        g_rows, row_elems, chunk_rows = 96, 130, 40
+        own = torch.from_numpy((1000.0 * (rank + 1) + np.arange(g_rows, dtype=np.float32)[:, None]
+                                + np.arange(row_elems, dtype=np.float32)[None, :] / 1024.0).astype(np.float32))
+        methods = [m for m in methods if m != 'ipc']
+        ctx = None
+    else:
+        dsc, B, ctx, x = gpu
+        g_rows, row_elems, chunk_rows = rows, 2 * bins, min(args.gather_chunk_rows, rows)
+    shard_bytes = g_rows * row_elems * 4
+    out = {'layout': f'dest[{world}][{g_rows}][{row_elems}] f32, rank-major = concatenation of the shards', 'shard_bytes': shard_bytes,
+           'chunk_rows': chunk_rows, 'backend': args.backend, 'variants': {}}
+
+    dev_dest = host_dest = None
+    x_chunks = None
+    if gpu is not None:
+        import ctypes
+        dev_dest = shard.DeviceDest(ctx, world, rank, g_rows, row_elems)
+        chunks = shard.chunk_bounds(g_rows, chunk_rows)
+        x_ptr = x._c_ptr.contents.data
+
+        def x_view(r0, n):
+            shp = (ctypes.c_int * 2)(n, N_FFT)
+            return B.dsc_tensor_from_device_ptr(ctx, x_ptr + r0 * N_FFT * 4, n * N_FFT * 4, 2, shp, int(dsc.Dtype.F32))
+        x_chunks = [x_view(r0, n) for r0, n in chunks]
+        out_chunks = [dev_dest.own_slot_tensor(r0, n, dsc.Dtype.C32, bins) for r0, n in chunks]
+        if not on_device:
+            host_dest = torch.empty((world, g_rows, row_elems), dtype=torch.float32)
+    else:
+        host_dest = torch.empty((world, g_rows, row_elems), dtype=torch.float32)
+
+    def run(method, with_compute):
+        """One pass over the chunks: [transform chunk i ->] push chunk i; finish.  Returns seconds (max over ranks)."""
+        use_dev = gpu is not None and (on_device or method == 'ipc')
+        dest = dev_dest.tensor if use_dev else host_dest
+        g = shard.ShardGather(dist, dest, chunk_rows, method=method, ctx=ctx, dest_ptr=dev_dest.ptr if use_dev else None)
+        try:
+            barrier_sync()
+            t0 = time.perf_counter()
+            for i, (r0, n) in enumerate(g.chunks):
+                if gpu is None:
+                    if with_compute:
+                        dest[rank, r0:r0 + n] = own[r0:r0 + n]
+                else:
+                    if with_compute:
+                        B.dsc_rfft(ctx, x_chunks[i], out_chunks[i], -1, -1)        # writes this rank's slot in place
+                    if not use_dev and with_compute:
+                        # host staging (gloo rehearsal on one GPU): chunk i leaves the device before it travels
+                        B.dsc_copy_to_host(ctx, out_chunks[i], dest[rank, r0:r0 + n].data_ptr(), n * row_elems * 4)
+                g.push(i)
+            g.finish()
+            dt = time.perf_counter() - t0
+            td = torch.tensor([dt], dtype=torch.float64, device='cuda' if on_device else 'cpu')
+            dist.all_reduce(td, op=dist.ReduceOp.MAX)
+            return float(td.item()), g.verify()
+        finally:
+            g.close()
+
+    for m in methods:
+        try:
+            target = dev_dest.tensor if (gpu is not None and (on_device or m == 'ipc')) else host_dest
+            target.fill_(-1.0)                            # every method must fill the destination itself
+            if gpu is not None:
+                torch.cuda.synchronize()
+            run(m, True)                                  # warm-up: communicator, IPC mappings, clocks
+            target.fill_(-1.0)
+            if gpu is not None:
+                torch.cuda.synchronize()
+            t_pipe, v = run(m, True)
+            t_only, v2 = run(m, False)
+            out['variants'][m] = {
+                'pipelined_ms': round(t_pipe * 1e3, 3), 'ms': round(t_only * 1e3, 3),
+                'recv_GBps_per_gpu': round((world - 1) * shard_bytes / t_only / 1e9, 2),
+                'verified': bool(v['verified'] and v2['verified']), 'rows_sampled_per_slot': v['rows_sampled_per_slot'],
+                'memory': 'device' if (gpu is not None and (on_device or m == 'ipc')) else 'host (staging)' if gpu is not None else 'host',
+            }
+        except Exception as e:
+            out['variants'][m] = {'error': repr(e)[:300], 'verified': False}
+    if gpu is not None:
+        for t in x_chunks:
+            B.dsc_tensor_free(ctx, t)
+        dev_dest.free()
+    ok = [m for m in methods if out['variants'].get(m, {}).get('verified')]
+    head = out['variants'].get('allgather') if 'allgather' in ok else (out['variants'][ok[0]] if ok else None)
+    if head is not None:
+        out.update({'ms': head['ms'], 'recv_GBps_per_gpu': head['recv_GBps_per_gpu'], 'pipelined_ms': head['pipelined_ms'],
+                    'method': 'allgather' if 'allgather' in ok else ok[0]})
+    out['verified'] = bool(methods) and len(ok) == len(methods)
+    out['note'] = ('separate phase, not included in value.  ms = exchange alone (shards already computed); pipelined_ms = transforms '
+                   'of all chunks + exchange, chunk i travelling while chunk i+1 is transformed; verified = every slot of every '
+                   "rank's destination equals its owner's shard (checksum + sample rows, bit exact)")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -105,7 +212,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-kernels', action='store_true', help='skip the untimed-for-value irfft / fused-filter measurements')
     ap.add_argument('--no-allgather', action='store_true')
-    ap.add_argument('--allgather-timeout', type=float, default=180.0, help='seconds the separate RCCL all-gather phase may take before it is abandoned')
+    ap.add_argument('--allgather-timeout', type=float, default=240.0, help='seconds the separate shard-reassembly phase may take before it is abandoned (every rank then exits 3)')
+    ap.add_argument('--gather-methods', default='allgather,p2p,ipc', help='exchange methods of dsc_amd/shard.py to run and verify, in this order')
+    ap.add_argument('--gather-chunk-rows', type=int, default=1024, help='rows per exchange step of the chunked methods')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (gloo for the CPU dry run)')
     ap.add_argument('--dry-run', action='store_true', help='exercise the multi-process plumbing without a GPU (tests)')
     ap.add_argument('--share-device', action='store_true', help='testing aid: every rank uses device 0 (rehearse N > 1 on a one-GPU box; use with --backend gloo)')
@@ -276,55 +385,30 @@ def main():
     else:
         line = None
 
-    # A collective that never returns must not cost the measurement above: past the deadline every rank leaves
-    # (rank 0 prints the line first, with the reason in `allgather`).
+    # A collective that never returns must not cost the measurement above: past the deadline rank 0 prints the line it
+    # has (with the reason in `allgather`) and EVERY rank exits non-zero, so that the hang is visible to the launcher.
+    printed = [False]
+
     def deadline(seconds, what):
         def bail():
             if rank == 0 and not printed[0]:
-                line['allgather'] = {'error': f'{what} did not finish within {seconds:.0f} s; skipped'}
+                line.update(extra)
+                line.setdefault('allgather', {})['error'] = f'{what} did not finish within {seconds:.0f} s; abandoned'
                 print(json.dumps(line), flush=True)
-            os._exit(0)
+            os._exit(3)
         t = threading.Timer(seconds, bail)
         t.daemon = True
         t.start()
         return t
 
-    printed = [False]
-    # ---- all-gather of the output shards over xGMI: its own phase, never part of `value`
-    if dist is not None and not args.dry_run and not args.no_allgather and args.backend == 'nccl':
-        guard = deadline(args.allgather_timeout, 'RCCL all-gather phase')
+    # ---- reassembly of the output shards: its own phase, never part of `value`
+    if dist is not None and not args.no_allgather:
+        guard = deadline(args.allgather_timeout, 'shard reassembly phase')
         try:
-            chunk_rows = 1024
-            bins = N_FFT // 2 + 1
-
-            class _DevView:          # zero-copy torch view of arena memory
-                def __init__(self, ptr, n_f32):
-                    self.__cuda_array_interface__ = {'shape': (n_f32,), 'typestr': '<f4', 'data': (ptr, False), 'version': 2}
-
-            base = out._c_ptr.contents.data
-            recv = torch.empty((world, chunk_rows * bins * 2), dtype=torch.float32, device='cuda')
-            views = [torch.as_tensor(_DevView(base + c * bins * 8, chunk_rows * bins * 2), device='cuda')
-                     for c in range(0, rows, chunk_rows)]
-            dist.all_gather_into_tensor(recv, views[0])       # warm-up: communicator + buffers
-            barrier_sync()
-            g0 = time.perf_counter()
-            for v in views:
-                dist.all_gather_into_tensor(recv, v)
-            barrier_sync()
-            g = time.perf_counter() - g0
-            tg = torch.tensor([g], dtype=torch.float64, device='cuda')
-            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-            g = float(tg.item())
-            shard_bytes = rows * bins * 8
-            extra['allgather'] = {
-                'ms': round(g * 1e3, 3),
-                'recv_GBps_per_gpu': round((world - 1) * shard_bytes / g / 1e9, 1),
-                'shard_bytes': shard_bytes,
-                'note': 'RCCL all_gather_into_tensor of every c32 shard, 1024-row chunks into a reused buffer; '
-                        'separate phase, not included in value',
-            }
+            extra['allgather'] = gather_phase(args, dist, world, rank, rows, barrier_sync,
+                                              None if args.dry_run else (dsc, B, ctx, x))
         except Exception as e:       # the metric must survive a collective problem
-            extra['allgather'] = {'error': repr(e)[:200]}
+            extra['allgather'] = {'error': repr(e)[:300]}
         guard.cancel()
 
     if rank == 0:

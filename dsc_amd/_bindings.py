@@ -144,4 +144,19 @@ dsc_timer_stop = _sig('dsc_timer_stop', c_float, _DscCtx)
 dsc_filter_fft = _sig('dsc_filter_fft', _DscTensor_p, _DscCtx, _DscTensor_p, _DscTensor_p, _DscTensor_p)
 dsc_last_fft_path = _sig('dsc_last_fft_path', c_char_p, _DscCtx)
 
+
+class _DscIpcHandle(Structure):        # include/dsc_mi355x.h section C
+    _fields_ = [('bytes', c_uint8 * 64)]
+
+
+dsc_device_alloc = _sig('dsc_device_alloc', c_void_p, _DscCtx, c_size_t)
+dsc_device_free = _sig('dsc_device_free', None, _DscCtx, c_void_p)
+dsc_tensor_from_device_ptr = _sig('dsc_tensor_from_device_ptr', _DscTensor_p, _DscCtx, c_void_p, c_size_t, c_int, POINTER(c_int), c_uint8)
+dsc_ipc_export = _sig('dsc_ipc_export', c_int, _DscCtx, c_void_p, POINTER(_DscIpcHandle))
+dsc_ipc_open = _sig('dsc_ipc_open', c_void_p, _DscCtx, POINTER(_DscIpcHandle))
+dsc_ipc_close = _sig('dsc_ipc_close', c_int, _DscCtx, c_void_p)
+dsc_peer_lanes = _sig('dsc_peer_lanes', c_int)
+dsc_peer_push = _sig('dsc_peer_push', c_int, _DscCtx, c_void_p, c_void_p, c_size_t, c_int)
+dsc_peer_wait = _sig('dsc_peer_wait', c_int, _DscCtx)
+
 EXPORTS = [n for n in dir() if n.startswith('dsc_') and n != 'dsc_api']

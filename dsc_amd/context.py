@@ -31,6 +31,11 @@ def init(main_mem: int, scratch_mem: int, device: int = None):
     _ctx_instance = _DscContext(main_mem, scratch_mem)
 
 
+def _current():
+    """The live context object or None — never creates one (Tensor.__del__ uses this)."""
+    return _ctx_instance
+
+
 def clear():
     if _ctx_instance is not None:
         _ctx_instance.clear()
@@ -57,6 +62,7 @@ def last_fft_path() -> str:
 class _DscContext:
     def __init__(self, main_mem: int, scratch_mem: int):
         self._ctx = B.dsc_ctx_init(main_mem, scratch_mem)
+        self.epoch = 0          # bumped by clear(): handles created before a clear are dead and must not be freed again
 
     def __del__(self):
         if B is not None and self._ctx:
@@ -64,4 +70,5 @@ class _DscContext:
             self._ctx = None
 
     def clear(self):
+        self.epoch += 1
         B.dsc_ctx_clear(self._ctx)

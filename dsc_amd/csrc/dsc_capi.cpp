@@ -56,11 +56,22 @@ extern "C" dsc_ctx *dsc_ctx_init(size_t main_mem, size_t scratch_mem) {
     return ctx;
 }
 
+// A header the caller has seen: out of circulation until DSC_HEADER_QUARANTINE younger ones have been retired.
+static void retire_header(dsc_ctx *ctx, dsc_tensor *t) {
+    t->buffer = nullptr;
+    t->data = nullptr;
+    ctx->quarantine.push_back(t);
+    if (ctx->quarantine.size() > DSC_HEADER_QUARANTINE) {
+        ctx->tensor_pool.push_back(ctx->quarantine.front());
+        ctx->quarantine.pop_front();
+    }
+}
+
 static void release_headers(dsc_ctx *ctx) {
     for (dsc_tensor *t : ctx->live_tensors) {
         dsc_buffer_rec *rec = (dsc_buffer_rec *) t->buffer;
         if (rec != nullptr && --rec->pub.refs == 0) delete rec;
-        ctx->tensor_pool.push_back(t);
+        retire_header(ctx, t);
     }
     ctx->live_tensors.clear();
 }
@@ -75,7 +86,9 @@ extern "C" void dsc_ctx_free(dsc_ctx *ctx) {
     DSC_LOG_INFO("freeing context %p: main mem %ldMB, scratch mem %ldMB", (void *) ctx,
                  (long) (ctx->main.capacity() >> 20), (long) (ctx->scratch.capacity() >> 20));
     release_headers(ctx);
+    dsc_peer_release(ctx);
     for (dsc_tensor *t : ctx->tensor_pool) delete t;
+    for (dsc_tensor *t : ctx->quarantine) delete t;
     for (auto &plan : ctx->fft_plans) { delete plan; plan = nullptr; }
     HIP_CHECK(hipFree(ctx->main_buf));
     HIP_CHECK(hipFree(ctx->scratch_buf));
@@ -192,20 +205,38 @@ extern "C" dsc_tensor *dsc_tensor_4d(dsc_ctx *ctx, dsc_dtype dtype, int d1, int 
     return dsc_new_tensor(ctx, 4, shape, dtype, nullptr);
 }
 
-// dsc.cpp:293-303.  Python's __del__ may free twice or after dsc_ctx_clear: ignore those.
+// dsc.cpp:293-303.  Python's __del__ may free twice or after dsc_ctx_clear: those find the header retired (not live)
+// and are ignored; the header's address is not handed out again while such stale handles are plausible (retire_header).
 extern "C" void dsc_tensor_free(dsc_ctx *ctx, dsc_tensor *x) {
-    if (x == nullptr) return;
+    if (x == nullptr || ctx == nullptr) return;
     auto it = ctx->live_tensors.find(x);
     if (it == ctx->live_tensors.end()) return;
     ctx->live_tensors.erase(it);
     dsc_buffer_rec *rec = (dsc_buffer_rec *) x->buffer;
     if (--rec->pub.refs == 0) {
-        ctx->main.free(rec->dev);
+        if (!rec->external) ctx->main.free(rec->dev);
         delete rec;
     }
-    x->buffer = nullptr;
-    x->data = nullptr;
-    ctx->tensor_pool.push_back(x);
+    retire_header(ctx, x);
+}
+
+// dsc_tensor_from_device_ptr: an ordinary header whose buffer record points at memory the caller owns.
+dsc_tensor *dsc_new_tensor_over(dsc_ctx *ctx, void *ptr, size_t nbytes, int n_dim, const int *shape, dsc_dtype dtype) {
+    DSC_ASSERT(n_dim > 0 && n_dim <= DSC_MAX_DIMS);
+    DSC_ASSERT(dtype < 4);
+    long long ne = 1;
+    for (int i = 0; i < n_dim; ++i) {
+        DSC_ASSERT(shape[i] > 0);
+        ne *= shape[i];
+    }
+    DSC_ASSERT(ne <= 0x7fffffffLL);
+    DSC_ASSERT((size_t) ne * dsc_dtype_size(dtype) <= nbytes);
+    dsc_buffer_rec *rec = new dsc_buffer_rec();
+    rec->pub.refs = 0;
+    rec->dev = (char *) ptr;
+    rec->nbytes = nbytes;
+    rec->external = true;
+    return dsc_new_tensor_in(ctx, n_dim, shape, dtype, &rec->pub, false);
 }
 
 extern "C" void dsc_copy_from_host(dsc_ctx *ctx, dsc_tensor *dst, const void *src, size_t nbytes) {

@@ -8,6 +8,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <deque>
 #include <map>
 #include <unordered_map>
 #include <unordered_set>
@@ -43,6 +44,7 @@
 #define DSC_ALIGN_UP(x, y) (((x) + (y) - 1) & ~((size_t) (y) - 1))
 #define DSC_DEVICE_ALIGN ((size_t) 256)
 #define DSC_MAX_FFT_PLANS 16                     // dsc/src/dsc.cpp:19-21
+#define DSC_HEADER_QUARANTINE ((size_t) 65536)   // freed tensor headers (64 B each) kept out of circulation
 
 static inline size_t dsc_dtype_size(dsc_dtype t) {   // dsc_dtype.h:58-63
     static const size_t sz[4] = {4, 8, 8, 16};
@@ -107,6 +109,7 @@ struct dsc_buffer_rec {
     dsc_tensor_buffer pub;
     char *dev;                // arena block (NULL for buffers living in scratch)
     size_t nbytes;
+    bool external = false;    // caller-owned device memory (dsc_tensor_from_device_ptr): never returned to the arena
 };
 
 // A plan = device twiddle tables for one (n, fft_type, precision): dsc_fft.h:18-27.
@@ -147,15 +150,26 @@ struct dsc_ctx {
     dsc_scratch_arena scratch;
     dsc_fft_plan *fft_plans[DSC_MAX_FFT_PLANS];
     std::unordered_set<dsc_tensor *> live_tensors;     // tolerate double frees (tensor.py __del__)
-    std::vector<dsc_tensor *> tensor_pool;             // recycled headers
+    // Header recycling.  A header address handed to the caller is a handle the caller may still hold after freeing it
+    // (Python's __del__ frees twice; handles outlive dsc_ctx_clear): reusing the address at once would let such a
+    // stale dsc_tensor_free release a NEW tensor's block.  Freed user-visible headers therefore wait in `quarantine`
+    // until DSC_HEADER_QUARANTINE younger ones have been freed; only headers that never left the library (scratch
+    // temporaries of an operator) go straight back to `tensor_pool`.
+    std::deque<dsc_tensor *> quarantine;
+    std::vector<dsc_tensor *> tensor_pool;             // headers safe to hand out again
     const char *last_fft_path;
     int n_cu;
     dsc_tracer tracer;
+    std::vector<hipStream_t> peer_streams;             // copy lanes of dsc_peer_push (peer.cpp), created on first use
+    hipEvent_t peer_ready = nullptr;
 };
 
 // internal helpers shared by the C-ABI translation units
 dsc_tensor *dsc_new_tensor_in(dsc_ctx *ctx, int n_dim, const int *shape, dsc_dtype dtype,
                               dsc_tensor_buffer *buffer, bool in_scratch);
+// header over caller-owned device memory (dsc_tensor_from_device_ptr): the buffer record does not own an arena block
+dsc_tensor *dsc_new_tensor_over(dsc_ctx *ctx, void *ptr, size_t nbytes, int n_dim, const int *shape, dsc_dtype dtype);
+void dsc_peer_release(dsc_ctx *ctx);
 
 // RAII scope placed at the top of an operator entry point: no cost beyond a branch unless recording.
 void dsc_trace_begin(dsc_ctx *ctx, const char *name, const char *cat, const dsc_tensor *a, const dsc_tensor *b, int i0, int i1);

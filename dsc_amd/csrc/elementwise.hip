@@ -43,10 +43,10 @@ template<typename Tin>
 void cast_from(const void *in, void *out, int out_dtype, long long ne, dim3 grid, hipStream_t s) {
     const Tin *x = (const Tin *) in;
     switch (out_dtype) {
-        case 0: hipLaunchKernelGGL((cast_kernel<Tin, float>), grid, dim3(256), 0, s, x, (float *) out, ne); break;
-        case 1: hipLaunchKernelGGL((cast_kernel<Tin, double>), grid, dim3(256), 0, s, x, (double *) out, ne); break;
-        case 2: hipLaunchKernelGGL((cast_kernel<Tin, cx<float>>), grid, dim3(256), 0, s, x, (cx<float> *) out, ne); break;
-        default: hipLaunchKernelGGL((cast_kernel<Tin, cx<double>>), grid, dim3(256), 0, s, x, (cx<double> *) out, ne); break;
+        case 0: DSC_LAUNCH((cast_kernel<Tin, float>), grid, dim3(256), 0, s, x, (float *) out, ne); break;
+        case 1: DSC_LAUNCH((cast_kernel<Tin, double>), grid, dim3(256), 0, s, x, (double *) out, ne); break;
+        case 2: DSC_LAUNCH((cast_kernel<Tin, cx<float>>), grid, dim3(256), 0, s, x, (cx<float> *) out, ne); break;
+        default: DSC_LAUNCH((cast_kernel<Tin, cx<double>>), grid, dim3(256), 0, s, x, (cx<double> *) out, ne); break;
     }
 }
 
@@ -130,12 +130,12 @@ bool binary_fast(const T *pa, const T *pb, T *po, const dsc_bcast_args &g, dim3 
     const unsigned ne = (unsigned) g.ne, sm = (unsigned) g.small_ne;
     constexpr unsigned V = 16 / sizeof(T);
     if (g.fast == 1 && V > 1 && ne % V == 0 && (((size_t) pa | (size_t) pb | (size_t) po) & 15) == 0) {
-        hipLaunchKernelGGL((binary_same_vec_kernel<T, OP>), stream_grid(ne / V), dim3(256), 0, s, pa, pb, po, ne / V);
+        DSC_LAUNCH((binary_same_vec_kernel<T, OP>), stream_grid(ne / V), dim3(256), 0, s, pa, pb, po, ne / V);
         return true;
     }
-    if (g.fast == 1) hipLaunchKernelGGL((binary_fast_kernel<T, OP, 1>), grid, dim3(256), 0, s, pa, pb, po, ne, sm);
-    else if (g.fast == 2) hipLaunchKernelGGL((binary_fast_kernel<T, OP, 2>), grid, dim3(256), 0, s, pa, pb, po, ne, sm);
-    else hipLaunchKernelGGL((binary_fast_kernel<T, OP, 3>), grid, dim3(256), 0, s, pa, pb, po, ne, sm);
+    if (g.fast == 1) DSC_LAUNCH((binary_fast_kernel<T, OP, 1>), grid, dim3(256), 0, s, pa, pb, po, ne, sm);
+    else if (g.fast == 2) DSC_LAUNCH((binary_fast_kernel<T, OP, 2>), grid, dim3(256), 0, s, pa, pb, po, ne, sm);
+    else DSC_LAUNCH((binary_fast_kernel<T, OP, 3>), grid, dim3(256), 0, s, pa, pb, po, ne, sm);
     return true;
 }
 
@@ -148,10 +148,10 @@ void binary_typed(const void *a, const void *b, void *out, int op, const dsc_bca
     if (op == 2 && binary_fast<T, 2>(pa, pb, po, g, grid, s)) return;
     if (op == 3 && binary_fast<T, 3>(pa, pb, po, g, grid, s)) return;
     switch (op) {
-        case 0: hipLaunchKernelGGL((binary_kernel<T, 0>), grid, dim3(256), 0, s, pa, pb, po, g); break;
-        case 1: hipLaunchKernelGGL((binary_kernel<T, 1>), grid, dim3(256), 0, s, pa, pb, po, g); break;
-        case 2: hipLaunchKernelGGL((binary_kernel<T, 2>), grid, dim3(256), 0, s, pa, pb, po, g); break;
-        default: hipLaunchKernelGGL((binary_kernel<T, 3>), grid, dim3(256), 0, s, pa, pb, po, g); break;
+        case 0: DSC_LAUNCH((binary_kernel<T, 0>), grid, dim3(256), 0, s, pa, pb, po, g); break;
+        case 1: DSC_LAUNCH((binary_kernel<T, 1>), grid, dim3(256), 0, s, pa, pb, po, g); break;
+        case 2: DSC_LAUNCH((binary_kernel<T, 2>), grid, dim3(256), 0, s, pa, pb, po, g); break;
+        default: DSC_LAUNCH((binary_kernel<T, 3>), grid, dim3(256), 0, s, pa, pb, po, g); break;
     }
 }
 
@@ -184,11 +184,11 @@ template<typename Tin>
 void unary_typed(const void *in, void *out, int op, long long ne, dim3 grid, hipStream_t s) {
     const Tin *x = (const Tin *) in;
     switch (op) {
-        case 0: hipLaunchKernelGGL((unary_kernel<Tin, 0>), grid, dim3(256), 0, s, x, out, ne); break;
-        case 1: hipLaunchKernelGGL((unary_kernel<Tin, 1>), grid, dim3(256), 0, s, x, out, ne); break;
-        case 2: hipLaunchKernelGGL((unary_kernel<Tin, 2>), grid, dim3(256), 0, s, x, out, ne); break;
-        case 3: hipLaunchKernelGGL((unary_kernel<Tin, 3>), grid, dim3(256), 0, s, x, out, ne); break;
-        default: hipLaunchKernelGGL((unary_kernel<Tin, 4>), grid, dim3(256), 0, s, x, out, ne); break;
+        case 0: DSC_LAUNCH((unary_kernel<Tin, 0>), grid, dim3(256), 0, s, x, out, ne); break;
+        case 1: DSC_LAUNCH((unary_kernel<Tin, 1>), grid, dim3(256), 0, s, x, out, ne); break;
+        case 2: DSC_LAUNCH((unary_kernel<Tin, 2>), grid, dim3(256), 0, s, x, out, ne); break;
+        case 3: DSC_LAUNCH((unary_kernel<Tin, 3>), grid, dim3(256), 0, s, x, out, ne); break;
+        default: DSC_LAUNCH((unary_kernel<Tin, 4>), grid, dim3(256), 0, s, x, out, ne); break;
     }
 }
 
@@ -272,12 +272,12 @@ void region_typed(const void *src, void *dst, const dsc_region &r, bool scatter,
     if (r.count[3] >= 128 && rows * ((r.count[3] + 255) / 256) < (1LL << 31)) {
         const unsigned chunks = (unsigned) ((r.count[3] + 255) / 256);
         const dim3 grid((unsigned) (rows * chunks));
-        if (scatter) hipLaunchKernelGGL((region_rows_kernel<E, true>), grid, dim3(256), 0, s, ps, pd, r, chunks, dense_ne);
-        else         hipLaunchKernelGGL((region_rows_kernel<E, false>), grid, dim3(256), 0, s, ps, pd, r, chunks, dense_ne);
+        if (scatter) DSC_LAUNCH((region_rows_kernel<E, true>), grid, dim3(256), 0, s, ps, pd, r, chunks, dense_ne);
+        else         DSC_LAUNCH((region_rows_kernel<E, false>), grid, dim3(256), 0, s, ps, pd, r, chunks, dense_ne);
     } else {
         const dim3 grid = stream_grid(r.ne);
-        if (scatter) hipLaunchKernelGGL((region_flat_kernel<E, true>), grid, dim3(256), 0, s, ps, pd, r, dense_ne);
-        else         hipLaunchKernelGGL((region_flat_kernel<E, false>), grid, dim3(256), 0, s, ps, pd, r, dense_ne);
+        if (scatter) DSC_LAUNCH((region_flat_kernel<E, true>), grid, dim3(256), 0, s, ps, pd, r, dense_ne);
+        else         DSC_LAUNCH((region_flat_kernel<E, false>), grid, dim3(256), 0, s, ps, pd, r, dense_ne);
     }
 }
 
@@ -322,7 +322,7 @@ template<typename E>
 void transpose_typed(const void *in, void *out, long long batch, int rows, int cols, hipStream_t s) {
     const unsigned tiles_c = (cols + 31) / 32, tiles_r = (rows + 31) / 32;
     const unsigned long long blocks = (unsigned long long) batch * tiles_c * tiles_r;
-    hipLaunchKernelGGL((transpose_last2_kernel<E>), dim3((unsigned) blocks), dim3(256), 0, s, (const E *) in, (E *) out, rows, cols, tiles_c,
+    DSC_LAUNCH((transpose_last2_kernel<E>), dim3((unsigned) blocks), dim3(256), 0, s, (const E *) in, (E *) out, rows, cols, tiles_c,
                        tiles_r);
 }
 

@@ -61,13 +61,12 @@ __global__ __launch_bounds__(1024) void c2c32k_kernel(const f2 *__restrict__ z, 
 void dsc_launch_fft32k_c32(const void *z, void *Z, int batch, int in_pitch, int in_len, bool inverse, const void *aux, int n_cu,
                            hipStream_t stream) {
     if (batch <= 0) return;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void) hipFuncSetAttribute((const void *) c2c32k_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        (void) hipFuncSetAttribute((const void *) c2c32k_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        attr_set = true;
+    static unsigned long long attr_devices = 0;
+    if (dsc_first_use_on_device(attr_devices)) {
+        DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) c2c32k_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+        DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) c2c32k_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     }
     const int grid = batch < n_cu ? batch : n_cu;
-    if (inverse) hipLaunchKernelGGL(c2c32k_kernel<true>, dim3(grid), dim3(1024), kLdsBytes, stream, (const f2 *) z, (f2 *) Z, batch, (const f2 *) aux, in_pitch, in_len);
-    else         hipLaunchKernelGGL(c2c32k_kernel<false>, dim3(grid), dim3(1024), kLdsBytes, stream, (const f2 *) z, (f2 *) Z, batch, (const f2 *) aux, in_pitch, in_len);
+    if (inverse) DSC_LAUNCH(c2c32k_kernel<true>, dim3(grid), dim3(1024), kLdsBytes, stream, (const f2 *) z, (f2 *) Z, batch, (const f2 *) aux, in_pitch, in_len);
+    else         DSC_LAUNCH(c2c32k_kernel<false>, dim3(grid), dim3(1024), kLdsBytes, stream, (const f2 *) z, (f2 *) Z, batch, (const f2 *) aux, in_pitch, in_len);
 }

@@ -303,20 +303,19 @@ void launch_lines(const dsc_fft_lines_args &a, dsc_fft_mode mode, hipStream_t st
     const long long tiles = (a.n_lines + C - 1) / C;
     const size_t lds = 2 * (size_t) p.C * p.P * sizeof(cx<T>) + (size_t) p.C * 20;      // two images + per-line base tables
     dim3 grid((unsigned) tiles), block(threads);
-    static bool attr_set = false;          // dynamic LDS above 64 KiB must be opted into, once per kernel
-    if (!attr_set) {
+    static unsigned long long attr_devices = 0;          // dynamic LDS above 64 KiB must be opted into, once per kernel
+    if (dsc_first_use_on_device(attr_devices)) {
         const int max_lds = 2 * kTileBytes + 8192;
-        (void) hipFuncSetAttribute((const void *) fft_lines_kernel<T, DSC_MODE_C2C>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-        (void) hipFuncSetAttribute((const void *) fft_lines_kernel<T, DSC_MODE_R2C_CAST>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-        (void) hipFuncSetAttribute((const void *) fft_lines_kernel<T, DSC_MODE_R2C_PACKED>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-        (void) hipFuncSetAttribute((const void *) fft_lines_kernel<T, DSC_MODE_C2R_PACKED>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-        attr_set = true;
+        DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) fft_lines_kernel<T, DSC_MODE_C2C>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) fft_lines_kernel<T, DSC_MODE_R2C_CAST>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) fft_lines_kernel<T, DSC_MODE_R2C_PACKED>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+        DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) fft_lines_kernel<T, DSC_MODE_C2R_PACKED>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     }
     switch (mode) {
-        case DSC_MODE_C2C:        hipLaunchKernelGGL((fft_lines_kernel<T, DSC_MODE_C2C>), grid, block, lds, stream, p); break;
-        case DSC_MODE_R2C_CAST:   hipLaunchKernelGGL((fft_lines_kernel<T, DSC_MODE_R2C_CAST>), grid, block, lds, stream, p); break;
-        case DSC_MODE_R2C_PACKED: hipLaunchKernelGGL((fft_lines_kernel<T, DSC_MODE_R2C_PACKED>), grid, block, lds, stream, p); break;
-        case DSC_MODE_C2R_PACKED: hipLaunchKernelGGL((fft_lines_kernel<T, DSC_MODE_C2R_PACKED>), grid, block, lds, stream, p); break;
+        case DSC_MODE_C2C:        DSC_LAUNCH((fft_lines_kernel<T, DSC_MODE_C2C>), grid, block, lds, stream, p); break;
+        case DSC_MODE_R2C_CAST:   DSC_LAUNCH((fft_lines_kernel<T, DSC_MODE_R2C_CAST>), grid, block, lds, stream, p); break;
+        case DSC_MODE_R2C_PACKED: DSC_LAUNCH((fft_lines_kernel<T, DSC_MODE_R2C_PACKED>), grid, block, lds, stream, p); break;
+        case DSC_MODE_C2R_PACKED: DSC_LAUNCH((fft_lines_kernel<T, DSC_MODE_C2R_PACKED>), grid, block, lds, stream, p); break;
     }
 }
 
@@ -424,7 +423,7 @@ void dsc_launch_fft_lines(const dsc_fft_lines_args &a, dsc_fft_mode mode, bool s
 void dsc_launch_fft_pack(const void *in, void *work, long long q_first, long long n_lines, long long inner, dsc_line_layout lin,
                          int L, int in_len, dsc_fft_mode mode, bool sp, hipStream_t stream) {
     const dim3 grid = flat_grid(n_lines * L), block(256);
-#define PACK(T, M) hipLaunchKernelGGL((fft_pack_kernel<T, M>), grid, block, 0, stream, in, (cx<T> *) work, q_first, n_lines, inner, lin, L, in_len)
+#define PACK(T, M) DSC_LAUNCH((fft_pack_kernel<T, M>), grid, block, 0, stream, in, (cx<T> *) work, q_first, n_lines, inner, lin, L, in_len)
     if (sp) {
         if (mode == DSC_MODE_C2C) PACK(float, DSC_MODE_C2C);
         else if (mode == DSC_MODE_R2C_CAST) PACK(float, DSC_MODE_R2C_CAST);
@@ -440,18 +439,18 @@ void dsc_launch_fft_pack(const void *in, void *work, long long q_first, long lon
 void dsc_launch_fft_c2r_prepass(const void *in, void *work, long long q_first, long long n_lines, long long inner, dsc_line_layout lin,
                                 int L, int in_len, const void *tw_real, bool sp, hipStream_t stream) {
     const dim3 grid = flat_grid(n_lines * L), block(256);
-    if (sp) hipLaunchKernelGGL(fft_c2r_prepass_kernel<float>, grid, block, 0, stream, (const cx<float> *) in, (cx<float> *) work,
+    if (sp) DSC_LAUNCH(fft_c2r_prepass_kernel<float>, grid, block, 0, stream, (const cx<float> *) in, (cx<float> *) work,
                                q_first, n_lines, inner, lin, L, in_len, (const cx<float> *) tw_real);
-    else    hipLaunchKernelGGL(fft_c2r_prepass_kernel<double>, grid, block, 0, stream, (const cx<double> *) in, (cx<double> *) work,
+    else    DSC_LAUNCH(fft_c2r_prepass_kernel<double>, grid, block, 0, stream, (const cx<double> *) in, (cx<double> *) work,
                                q_first, n_lines, inner, lin, L, in_len, (const cx<double> *) tw_real);
 }
 
 void dsc_launch_fft_r2c_postpass(const void *work, void *out, long long q_first, long long n_lines, long long inner, dsc_line_layout lout,
                                  int L, const void *tw_real, bool sp, hipStream_t stream) {
     const dim3 grid = flat_grid(n_lines * (L + 1LL)), block(256);
-    if (sp) hipLaunchKernelGGL(fft_r2c_postpass_kernel<float>, grid, block, 0, stream, (const cx<float> *) work, (cx<float> *) out,
+    if (sp) DSC_LAUNCH(fft_r2c_postpass_kernel<float>, grid, block, 0, stream, (const cx<float> *) work, (cx<float> *) out,
                                q_first, n_lines, inner, lout, L, (const cx<float> *) tw_real);
-    else    hipLaunchKernelGGL(fft_r2c_postpass_kernel<double>, grid, block, 0, stream, (const cx<double> *) work, (cx<double> *) out,
+    else    DSC_LAUNCH(fft_r2c_postpass_kernel<double>, grid, block, 0, stream, (const cx<double> *) work, (cx<double> *) out,
                                q_first, n_lines, inner, lout, L, (const cx<double> *) tw_real);
 }
 
@@ -460,13 +459,13 @@ void dsc_launch_fft_unpack(const void *work, void *out, long long q_first, long 
     const dim3 grid = flat_grid(n_lines * L), block(256);
     if (sp) {
         if (mode == DSC_MODE_C2R_PACKED)
-            hipLaunchKernelGGL((fft_unpack_kernel<float, DSC_MODE_C2R_PACKED>), grid, block, 0, stream, (const cx<float> *) work, out, q_first, n_lines, inner, lout, L, (float) scale);
+            DSC_LAUNCH((fft_unpack_kernel<float, DSC_MODE_C2R_PACKED>), grid, block, 0, stream, (const cx<float> *) work, out, q_first, n_lines, inner, lout, L, (float) scale);
         else
-            hipLaunchKernelGGL((fft_unpack_kernel<float, DSC_MODE_C2C>), grid, block, 0, stream, (const cx<float> *) work, out, q_first, n_lines, inner, lout, L, (float) scale);
+            DSC_LAUNCH((fft_unpack_kernel<float, DSC_MODE_C2C>), grid, block, 0, stream, (const cx<float> *) work, out, q_first, n_lines, inner, lout, L, (float) scale);
     } else {
         if (mode == DSC_MODE_C2R_PACKED)
-            hipLaunchKernelGGL((fft_unpack_kernel<double, DSC_MODE_C2R_PACKED>), grid, block, 0, stream, (const cx<double> *) work, out, q_first, n_lines, inner, lout, L, scale);
+            DSC_LAUNCH((fft_unpack_kernel<double, DSC_MODE_C2R_PACKED>), grid, block, 0, stream, (const cx<double> *) work, out, q_first, n_lines, inner, lout, L, scale);
         else
-            hipLaunchKernelGGL((fft_unpack_kernel<double, DSC_MODE_C2C>), grid, block, 0, stream, (const cx<double> *) work, out, q_first, n_lines, inner, lout, L, scale);
+            DSC_LAUNCH((fft_unpack_kernel<double, DSC_MODE_C2C>), grid, block, 0, stream, (const cx<double> *) work, out, q_first, n_lines, inner, lout, L, scale);
     }
 }

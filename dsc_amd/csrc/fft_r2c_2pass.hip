@@ -344,27 +344,26 @@ void launch_pair(const void *in, void *out, long long rows, void *work, const vo
     using C = cpx<R>;
     constexpr int L = 32 * B1 * 1024;
     constexpr int rl = rows_lds_bytes<R>(), cl = cols_lds_bytes<R, B1>();
-    static bool done = false;
-    if (!done) {
-        (void) hipFuncSetAttribute((const void *) two_pass_rows_kernel<R, B1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, rl);
-        (void) hipFuncSetAttribute((const void *) two_pass_rows_kernel<R, B1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, rl);
-        (void) hipFuncSetAttribute((const void *) two_pass_cols_kernel<R, B1, false, REAL>, hipFuncAttributeMaxDynamicSharedMemorySize, cl);
-        (void) hipFuncSetAttribute((const void *) two_pass_cols_kernel<R, B1, true, REAL>, hipFuncAttributeMaxDynamicSharedMemorySize, cl);
-        done = true;
+    static unsigned long long attr_devices = 0;
+    if (dsc_first_use_on_device(attr_devices)) {
+        DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) two_pass_rows_kernel<R, B1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, rl));
+        DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) two_pass_rows_kernel<R, B1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, rl));
+        DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) two_pass_cols_kernel<R, B1, false, REAL>, hipFuncAttributeMaxDynamicSharedMemorySize, cl));
+        DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) two_pass_cols_kernel<R, B1, true, REAL>, hipFuncAttributeMaxDynamicSharedMemorySize, cl));
     }
     const dim3 grid((unsigned) (rows * 2 * B1));          // L1 / 16 row groups = 1024 / NC column blocks = 2 B1 per transform
     constexpr int ext_b = REAL ? (int) sizeof(R) : (int) sizeof(C);           // bytes per external time-domain element
     constexpr long long full_row_b = (long long) L * sizeof(C);
     constexpr int out_bins = REAL ? L + 1 : L;
     if (!inverse) {
-        hipLaunchKernelGGL((two_pass_rows_kernel<R, B1, false>), grid, dim3(512), rl, stream, (const C *) in, (C *) work, (const C *) tw_full, (R) 1,
+        DSC_LAUNCH((two_pass_rows_kernel<R, B1, false>), grid, dim3(512), rl, stream, (const C *) in, (C *) work, (const C *) tw_full, (R) 1,
                            in_pitch * ext_b, (int) (in_len * ext_b));
-        hipLaunchKernelGGL((two_pass_cols_kernel<R, B1, false, REAL>), grid, dim3(512), cl, stream, (const C *) work, (C *) out, (const C *) tw_full,
+        DSC_LAUNCH((two_pass_cols_kernel<R, B1, false, REAL>), grid, dim3(512), cl, stream, (const C *) work, (C *) out, (const C *) tw_full,
                            (const C *) tw_real, (long long) out_bins, out_bins);
     } else {
-        hipLaunchKernelGGL((two_pass_cols_kernel<R, B1, true, REAL>), grid, dim3(512), cl, stream, (const C *) in, (C *) work, (const C *) tw_full,
+        DSC_LAUNCH((two_pass_cols_kernel<R, B1, true, REAL>), grid, dim3(512), cl, stream, (const C *) in, (C *) work, (const C *) tw_full,
                            (const C *) tw_real, in_pitch, in_len);
-        hipLaunchKernelGGL((two_pass_rows_kernel<R, B1, true>), grid, dim3(512), rl, stream, (const C *) work, (C *) out, (const C *) tw_full,
+        DSC_LAUNCH((two_pass_rows_kernel<R, B1, true>), grid, dim3(512), rl, stream, (const C *) work, (C *) out, (const C *) tw_full,
                            (R) (1.0 / (double) L), full_row_b, (int) full_row_b);                 // 2/(2n) (dsc_fft.h:232) = 1/n (:168-175)
     }
 }

@@ -761,34 +761,31 @@ void dsc_r2c64k_build_tables(void *host_dst) {
 
 void dsc_launch_rfft64k(const float *x, void *X, int batch, int in_pitch, int in_len, const void *aux, int n_cu, hipStream_t stream) {
     if (batch <= 0) return;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void) hipFuncSetAttribute((const void *) rfft64k_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        attr_set = true;
+    static unsigned long long attr_devices = 0;
+    if (dsc_first_use_on_device(attr_devices)) {
+        DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) rfft64k_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     }
     const int grid = batch < n_cu ? batch : n_cu;
-    hipLaunchKernelGGL(rfft64k_kernel, dim3(grid), dim3(1024), kLdsBytes, stream, x, (f2 *) X, batch, (const f2 *) aux, in_pitch, in_len PROBE_NULL);
+    DSC_LAUNCH(rfft64k_kernel, dim3(grid), dim3(1024), kLdsBytes, stream, x, (f2 *) X, batch, (const f2 *) aux, in_pitch, in_len PROBE_NULL);
 }
 
 void dsc_launch_irfft64k(const void *X, float *x, int batch, int in_pitch, int in_len, const void *aux, int n_cu, hipStream_t stream) {
     if (batch <= 0) return;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void) hipFuncSetAttribute((const void *) irfft64k_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        attr_set = true;
+    static unsigned long long attr_devices = 0;
+    if (dsc_first_use_on_device(attr_devices)) {
+        DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) irfft64k_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     }
     const int grid = batch < n_cu ? batch : n_cu;
-    hipLaunchKernelGGL(irfft64k_kernel, dim3(grid), dim3(1024), kLdsBytes, stream, (const f2 *) X, x, batch, (const f2 *) aux, in_pitch, in_len PROBE_NULL);
+    DSC_LAUNCH(irfft64k_kernel, dim3(grid), dim3(1024), kLdsBytes, stream, (const f2 *) X, x, batch, (const f2 *) aux, in_pitch, in_len PROBE_NULL);
 }
 void dsc_launch_filter64k(const float *s, const void *H, float *y, int batch, int in_pitch, int in_len, const void *aux, int n_cu,
                           hipStream_t stream) {
     if (batch <= 0) return;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void) hipFuncSetAttribute((const void *) filter64k_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        attr_set = true;
+    static unsigned long long attr_devices = 0;
+    if (dsc_first_use_on_device(attr_devices)) {
+        DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) filter64k_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     }
     const int grid = batch < n_cu ? batch : n_cu;
-    hipLaunchKernelGGL(filter64k_kernel, dim3(grid), dim3(1024), kLdsBytes, stream, s, (const f2 *) H, y, batch, (const f2 *) aux, in_pitch, in_len);
+    DSC_LAUNCH(filter64k_kernel, dim3(grid), dim3(1024), kLdsBytes, stream, s, (const f2 *) H, y, batch, (const f2 *) aux, in_pitch, in_len);
 }
 #endif  // DSC_R2C64K_HELPERS_ONLY

@@ -425,13 +425,12 @@ void launch_filter(const void *s, const void *H, void *y, long long n_lines, con
                    int in_len_b, hipStream_t stream) {
     using cfg = mid_cfg<R, B, TWO>;
     constexpr size_t lds = mid_lds_bytes<R, B, TWO>();
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void) hipFuncSetAttribute((const void *) fft_mid_filter_kernel<R, B, TWO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-        attr_set = true;
+    static unsigned long long attr_devices = 0;
+    if (dsc_first_use_on_device(attr_devices)) {
+        DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) fft_mid_filter_kernel<R, B, TWO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     }
     const long long groups = (n_lines + cfg::G - 1) / cfg::G;
-    hipLaunchKernelGGL((fft_mid_filter_kernel<R, B, TWO>), dim3((unsigned) groups), dim3(cfg::NT), lds, stream, (const R *) s,
+    DSC_LAUNCH((fft_mid_filter_kernel<R, B, TWO>), dim3((unsigned) groups), dim3(cfg::NT), lds, stream, (const R *) s,
                        (const cpx<R> *) H, (cpx<R> *) y, n_lines, (const cpx<R> *) tw_full, (const cpx<R> *) tw_real, in_pitch_b, in_len_b);
 }
 
@@ -567,13 +566,12 @@ template<typename R, int B, int MODE, bool INV>
 void launch_small_one(const void *in, void *out, long long n_lines, const void *tw_full, const void *tw_real, double scale, hipStream_t stream) {
     constexpr int G = small_cfg<R>::NT / B;
     constexpr size_t lds = small_lds_bytes<R, B>();
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void) hipFuncSetAttribute((const void *) fft_small_kernel<R, B, MODE, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-        attr_set = true;
+    static unsigned long long attr_devices = 0;
+    if (dsc_first_use_on_device(attr_devices)) {
+        DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) fft_small_kernel<R, B, MODE, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     }
     const long long groups = (n_lines + G - 1) / G;
-    hipLaunchKernelGGL((fft_small_kernel<R, B, MODE, INV>), dim3((unsigned) groups), dim3(small_cfg<R>::NT), lds, stream, in, out, n_lines,
+    DSC_LAUNCH((fft_small_kernel<R, B, MODE, INV>), dim3((unsigned) groups), dim3(small_cfg<R>::NT), lds, stream, in, out, n_lines,
                        (const cpx<R> *) tw_full, (const cpx<R> *) tw_real, (R) scale);
 }
 
@@ -593,13 +591,12 @@ void launch_pad(const void *in, void *out, long long n_lines, const void *tw_ful
                 int in_len_b, hipStream_t stream) {
     using cfg = mid_cfg<R, B, TWO>;
     constexpr size_t lds = mid_lds_bytes<R, B, TWO>();
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void) hipFuncSetAttribute((const void *) fft_mid_kernel<R, B, TWO, MODE, INV, PAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-        attr_set = true;
+    static unsigned long long attr_devices = 0;
+    if (dsc_first_use_on_device(attr_devices)) {
+        DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) fft_mid_kernel<R, B, TWO, MODE, INV, PAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     }
     const long long groups = (n_lines + cfg::G - 1) / cfg::G;
-    hipLaunchKernelGGL((fft_mid_kernel<R, B, TWO, MODE, INV, PAD>), dim3((unsigned) groups), dim3(cfg::NT), lds, stream, (const cpx<R> *) in,
+    DSC_LAUNCH((fft_mid_kernel<R, B, TWO, MODE, INV, PAD>), dim3((unsigned) groups), dim3(cfg::NT), lds, stream, (const cpx<R> *) in,
                        (cpx<R> *) out, n_lines, (const cpx<R> *) tw_full, (const cpx<R> *) tw_real, (R) scale, in_pitch_b, in_len_b);
 }
 

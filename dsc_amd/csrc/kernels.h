@@ -4,6 +4,36 @@
 
 #include <hip/hip_runtime.h>
 #include <cstddef>
+#include <cstdio>
+#include <cstdlib>
+
+// Error convention of the reference (dsc/include/dsc.h:14-28): message on stderr, exit.  Every kernel launch and every
+// attribute call goes through these: a refused launch (grid too large, LDS not granted, ...) must never return an
+// uninitialised tensor silently.
+#define DSC_KERNEL_CHECK(call)                                                                                   \
+    do {                                                                                                         \
+        hipError_t kerr_ = (call);                                                                               \
+        if (kerr_ != hipSuccess) {                                                                               \
+            fprintf(stderr, "HIP error %s:%d: %s -> %s\n", __FILE__, __LINE__, #call, hipGetErrorString(kerr_)); \
+            exit(EXIT_FAILURE);                                                                                  \
+        }                                                                                                        \
+    } while (0)
+#define DSC_LAUNCH(...)                        \
+    do {                                       \
+        hipLaunchKernelGGL(__VA_ARGS__);       \
+        DSC_KERNEL_CHECK(hipGetLastError());   \
+    } while (0)
+
+// Dynamic-LDS opt-ins are per device: true the first time a call site runs on the calling thread's current device
+// (one process per GPU is the design, but a host that drives several devices from one process stays correct).
+static inline bool dsc_first_use_on_device(unsigned long long &seen) {
+    int dev = 0;
+    DSC_KERNEL_CHECK(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (seen & bit) return false;
+    seen |= bit;
+    return true;
+}
 
 // A batch of 1-D lines inside a tensor.  Line q (0 <= q < n_lines) starts at element
 //   (q / inner) * outer_stride + (q % inner) * inner_stride

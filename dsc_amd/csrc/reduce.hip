@@ -160,6 +160,7 @@ void launch_op(const void *x, void *out, long long outer, int axis_n, long long 
     if (!(inner == 1 && axis_n >= 64) && n_out_all < 256 * 1024 && axis_n >= 128 && ws != nullptr) {
         long long n_seg = (512 * 1024 + n_out_all - 1) / n_out_all;
         if (n_seg > axis_n / 32) n_seg = axis_n / 32;
+        if (n_seg > 4096) n_seg = 4096;                 // grid.y (HIP allows 65535); a few thousand segments already fill the chip
         const size_t per = (size_t) n_out_all * (2 * sizeof(R) + sizeof(int));
         if (n_seg * per > ws_bytes) n_seg = (long long) (ws_bytes / per);
         if (n_seg >= 2) {
@@ -169,21 +170,21 @@ void launch_op(const void *x, void *out, long long outer, int axis_n, long long 
             R *pi = pr + n_seg * n_out_all;
             int *pidx = (int *) (pi + n_seg * n_out_all);
             const unsigned bx = (unsigned) ((n_out_all + 255) / 256);
-            hipLaunchKernelGGL((reduce_seg_kernel<R, CPLX, OP>), dim3(bx, (unsigned) n_seg), dim3(256), 0, s, x, pr, pi, pidx, outer,
+            DSC_LAUNCH((reduce_seg_kernel<R, CPLX, OP>), dim3(bx, (unsigned) n_seg), dim3(256), 0, s, x, pr, pi, pidx, outer,
                                axis_n, inner, seg_len);
-            hipLaunchKernelGGL((reduce_combine_kernel<R, CPLX, OP>), dim3(bx), dim3(256), 0, s, pr, pi, pidx, out, n_out_all,
+            DSC_LAUNCH((reduce_combine_kernel<R, CPLX, OP>), dim3(bx), dim3(256), 0, s, pr, pi, pidx, out, n_out_all,
                                (int) n_seg, axis_n);
             return;
         }
     }
     if (inner == 1 && axis_n >= 64) {
         long long blocks = outer < 256 * 16 ? outer : 256 * 16;
-        hipLaunchKernelGGL((reduce_row_kernel<R, CPLX, OP>), dim3((unsigned) blocks), dim3(256), 0, s, x, out, outer, axis_n);
+        DSC_LAUNCH((reduce_row_kernel<R, CPLX, OP>), dim3((unsigned) blocks), dim3(256), 0, s, x, out, outer, axis_n);
     } else {
         const long long n_out = outer * inner;
         long long blocks = (n_out + 255) / 256;
         if (blocks > 256 * 8) blocks = 256 * 8;
-        hipLaunchKernelGGL((reduce_seq_kernel<R, CPLX, OP>), dim3((unsigned) blocks), dim3(256), 0, s, x, out, outer, axis_n, inner);
+        DSC_LAUNCH((reduce_seq_kernel<R, CPLX, OP>), dim3((unsigned) blocks), dim3(256), 0, s, x, out, outer, axis_n, inner);
     }
 }
 

@@ -10,6 +10,7 @@ from typing import List, Tuple, Union
 import numpy as np
 
 from . import _bindings as B
+from .context import _current as _current_ctx
 from .context import _get_ctx
 from .dtype import DTYPE_CONVERSION_TABLES, DTYPE_TO_NP, NP_TO_DTYPE, Dtype, ScalarType
 
@@ -32,10 +33,17 @@ class Tensor:
         self._shape = tuple(c.shape[_DSC_MAX_DIMS - c.n_dim:])
         self._ne = c.ne
         self._c_ptr = c_ptr
+        # the context (and its clear() epoch) this handle belongs to: it is freed against THAT context only
+        self._owner = _current_ctx()
+        self._epoch = self._owner.epoch if self._owner is not None else -1
 
     def __del__(self):
+        # Never create a context from a destructor, never free into a context that has been cleared or replaced since
+        # this handle was made (dsc_ctx_clear already released it; its header address may belong to a new tensor).
         try:
-            B.dsc_tensor_free(_get_ctx(), self._c_ptr)
+            owner = self._owner
+            if owner is not None and owner is _current_ctx() and owner._ctx and owner.epoch == self._epoch:
+                B.dsc_tensor_free(owner._ctx, self._c_ptr)
         except Exception:      # interpreter teardown
             pass
 

@@ -218,6 +218,44 @@ dsc_tensor *dsc_filter_fft(dsc_ctx *ctx, const dsc_tensor *s, const dsc_tensor *
  * "generic_4step", ...): lets tests assert that the hand-written path really ran. */
 const char *dsc_last_fft_path(dsc_ctx *ctx);
 
+/* ---------------------------------------------------------------------------------------------
+ * Section C — multi-GPU reassembly of batch-sharded outputs.
+ *
+ * No reference counterpart: the reference has one backend (CPU, dsc/include/dsc_backend.h:11-13) and no communication
+ * layer.  Rows of a batched transform are independent, so rank r (one process per GPU) transforms rows
+ * [r*B/P, (r+1)*B/P) with no exchange on the data path; these entry points exist to put the P shards next to each
+ * other afterwards.  The gathered output of config 4 (65536 x 32769 c32) exceeds `int ne` (dsc.h:104) and therefore is
+ * a RAW device buffer, not a dsc_tensor.  dsc_amd/shard.py drives them (and the RCCL variants); plain C here.
+ */
+
+/* hipIpcMemHandle_t as bytes, so that no HIP type appears in a signature. */
+typedef struct dsc_ipc_handle { unsigned char bytes[64]; } dsc_ipc_handle;
+
+/* A device buffer of its own (hipMalloc on the context's device), outside both arenas: the gather destination
+ * [P x shard].  NULL on failure (this one reports instead of exiting: the caller sizes it from the world size). */
+void *dsc_device_alloc(dsc_ctx *ctx, size_t nbytes);
+void  dsc_device_free(dsc_ctx *ctx, void *ptr);
+
+/* A dsc_tensor header over `nbytes` of caller-owned device memory (e.g. this rank's slot of the gather destination, so
+ * that dsc_rfft writes its shard in place — no local copy).  The tensor does not own the bytes: dsc_tensor_free
+ * releases the header only, and the memory must outlive it. */
+dsc_tensor *dsc_tensor_from_device_ptr(dsc_ctx *ctx, void *ptr, size_t nbytes, int n_dim, const int *shape, dsc_dtype dtype);
+
+/* Export `ptr` (a dsc_device_alloc result) to the other ranks' processes / open another rank's export.  The mapped
+ * pointer addresses the PEER GPU's memory over xGMI (or the same GPU when ranks share one).  0 on success. */
+int   dsc_ipc_export(dsc_ctx *ctx, void *ptr, dsc_ipc_handle *out);
+void *dsc_ipc_open(dsc_ctx *ctx, const dsc_ipc_handle *handle);
+int   dsc_ipc_close(dsc_ctx *ctx, void *mapped);
+
+/* Direct push: copy `nbytes` from `src` (local) to `dst` (local or a dsc_ipc_open mapping) on copy lane `lane`
+ * (0 <= lane < dsc_peer_lanes(): one HIP stream per lane, i.e. one per xGMI link when lane = peer), ordered AFTER
+ * everything enqueued so far on the context's stream — the transform that produced `src` — and asynchronous to what
+ * is enqueued afterwards: the gather of chunk i overlaps the transform of chunk i+1.  0 on success. */
+int   dsc_peer_lanes(void);
+int   dsc_peer_push(dsc_ctx *ctx, void *dst, const void *src, size_t nbytes, int lane);
+/* Host waits until every push on every lane has landed (then exchange a barrier before peers read). */
+int   dsc_peer_wait(dsc_ctx *ctx);
+
 #ifdef __cplusplus
 }
 #endif

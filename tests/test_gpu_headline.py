@@ -175,6 +175,13 @@ def test_bench_two_ranks_on_one_gpu():
     assert j['n_gpus'] == 2 and j['config']['global_batch'] == 2048 and j['config']['kernel_path'] == 'r2c_64k_regs'
     assert j['parity']['rel_l2_vs_cpu_oracle'] <= 1e-5
     assert j['roofline']['achieved'] > 0 and 'cpu_baseline' not in j
+    # reassembly of the two shards of real dsc_rfft output: through host staging for the gloo collectives, and directly
+    # on the device (HIP IPC between the two processes) for the hand-rolled pushes; each proven against the owners' shards
+    g = j['allgather']
+    assert set(g['variants']) == {'allgather', 'p2p', 'ipc'}, g
+    for name, v in g['variants'].items():
+        assert v.get('verified') is True, (name, v)
+    assert g['variants']['ipc']['memory'] == 'device' and g['verified'] is True
 
 
 def test_f64_262144_register_path(dsc):

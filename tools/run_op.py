@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""tools/run_op.py <case> [--iters N] — run ONE operator case of the hot path N times (for rocprofv3) and print one JSON line
+with its algorithmic bytes and the HIP-event time per launch.  `--list` prints the case names.
+Used by tools/profile_families.sh; the summaries land in profiles/."""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+
+CASES = {}
+
+
+def case(name):
+    def deco(f):
+        CASES[name] = f
+        return f
+    return deco
+
+
+def _rfft_case(n, batch, f64=False, inverse=False):
+    def make(dsc, B, ctx, np):
+        rdt, cdt = (dsc.Dtype.F64, dsc.Dtype.C64) if f64 else (dsc.Dtype.F32, dsc.Dtype.C32)
+        npr = np.float64 if f64 else np.float32
+        rng = np.random.default_rng(3)
+        blk = rng.standard_normal((min(batch, 64), n)).astype(npr)
+        x = dsc.from_numpy(np.tile(blk, (batch // blk.shape[0], 1)))
+        X = dsc.empty((batch, n // 2 + 1), cdt)
+        B.dsc_rfft(ctx, x._c_ptr, X._c_ptr, -1, -1)
+        es = 8 if f64 else 4
+        nbytes = batch * (n * es + (n // 2 + 1) * 2 * es)
+        if inverse:
+            return (lambda: B.dsc_irfft(ctx, X._c_ptr, x._c_ptr, -1, -1)), nbytes, (x, X)
+        return (lambda: B.dsc_rfft(ctx, x._c_ptr, X._c_ptr, -1, -1)), nbytes, (x, X)
+    return make
+
+
+def _fft_case(n, batch, f64=False):
+    def make(dsc, B, ctx, np):
+        cdt = dsc.Dtype.C64 if f64 else dsc.Dtype.C32
+        npc = np.complex128 if f64 else np.complex64
+        rng = np.random.default_rng(4)
+        blk = (rng.standard_normal((min(batch, 64), n)) + 1j * rng.standard_normal((min(batch, 64), n))).astype(npc)
+        x = dsc.from_numpy(np.tile(blk, (batch // blk.shape[0], 1)))
+        X = dsc.empty((batch, n), cdt)
+        es = 16 if f64 else 8
+        return (lambda: B.dsc_fft(ctx, x._c_ptr, X._c_ptr, -1, -1)), 2 * batch * n * es, (x, X)
+    return make
+
+
+CASES['rfft64k'] = _rfft_case(65536, 8192)
+CASES['irfft64k'] = _rfft_case(65536, 8192, inverse=True)
+CASES['rfft_c5_f64_262144'] = _rfft_case(262144, 2048, f64=True)
+CASES['irfft_c5_f64_262144'] = _rfft_case(262144, 2048, f64=True, inverse=True)
+CASES['rfft_f32_131072'] = _rfft_case(131072, 4096)
+CASES['rfft_f32_524288'] = _rfft_case(524288, 1024)
+CASES['rfft_f32_1024'] = _rfft_case(1024, 524288)
+CASES['irfft_f32_1024'] = _rfft_case(1024, 524288, inverse=True)
+CASES['rfft_f32_4096'] = _rfft_case(4096, 131072)
+CASES['irfft_f32_4096'] = _rfft_case(4096, 131072, inverse=True)
+CASES['rfft_f32_16384'] = _rfft_case(16384, 32768)
+CASES['rfft_f32_256'] = _rfft_case(256, 2097152)
+CASES['rfft_f64_4096'] = _rfft_case(4096, 65536, f64=True)
+CASES['rfft_f32_32'] = _rfft_case(32, 16777216)          # generic LDS kernel (complex length < 32)
+CASES['fft_c32_32768'] = _fft_case(32768, 8192)
+CASES['fft_c32_4096'] = _fft_case(4096, 65536)
+
+
+@case('filter64k')
+def _filter(dsc, B, ctx, np):
+    rng = np.random.default_rng(5)
+    blk = rng.standard_normal((64, 65536)).astype(np.float32)
+    s = dsc.from_numpy(np.tile(blk, (64, 1)))
+    y = dsc.empty((4096, 65536), dsc.Dtype.F32)
+    H = dsc.from_numpy((rng.standard_normal(32769) + 1j * rng.standard_normal(32769)).astype(np.complex64))
+    return (lambda: B.dsc_filter_fft(ctx, s._c_ptr, H._c_ptr, y._c_ptr)), 4096 * 65536 * 8, (s, y, H)
+
+
+@case('filter_f32_4096')
+def _filter_mid(dsc, B, ctx, np):
+    rng = np.random.default_rng(5)
+    n, batch = 4096, 65536
+    blk = rng.standard_normal((64, n)).astype(np.float32)
+    s = dsc.from_numpy(np.tile(blk, (batch // 64, 1)))
+    y = dsc.empty((batch, n), dsc.Dtype.F32)
+    H = dsc.from_numpy((rng.standard_normal(n // 2 + 1) + 1j * rng.standard_normal(n // 2 + 1)).astype(np.complex64))
+    return (lambda: B.dsc_filter_fft(ctx, s._c_ptr, H._c_ptr, y._c_ptr)), batch * n * 8, (s, y, H)
+
+
+@case('rfft_axis0_4096x8192')
+def _axis0(dsc, B, ctx, np):
+    rng = np.random.default_rng(6)
+    n, cols = 4096, 8192
+    x = dsc.from_numpy(rng.standard_normal((n, cols)).astype(np.float32))
+    X = dsc.empty((n // 2 + 1, cols), dsc.Dtype.C32)
+    return (lambda: B.dsc_rfft(ctx, x._c_ptr, X._c_ptr, -1, 0)), cols * (n * 4 + (n // 2 + 1) * 8), (x, X)
+
+
+@case('rfft_axis0_256x131072')
+def _axis0_small(dsc, B, ctx, np):
+    rng = np.random.default_rng(6)
+    n, cols = 256, 131072
+    x = dsc.from_numpy(rng.standard_normal((n, cols)).astype(np.float32))
+    X = dsc.empty((n // 2 + 1, cols), dsc.Dtype.C32)
+    return (lambda: B.dsc_rfft(ctx, x._c_ptr, X._c_ptr, -1, 0)), cols * (n * 4 + (n // 2 + 1) * 8), (x, X)
+
+
+@case('mul_c32_bcast')
+def _mul(dsc, B, ctx, np):
+    S = dsc.empty((4096, 32769), dsc.Dtype.C32)
+    P = dsc.empty((4096, 32769), dsc.Dtype.C32)
+    H = dsc.from_numpy(np.ones(32769, np.complex64))
+    return (lambda: B.dsc_mul(ctx, S._c_ptr, H._c_ptr, P._c_ptr)), 4096 * 32769 * 16, (S, P, H)
+
+
+@case('sum_c32_axis0')
+def _sum0(dsc, B, ctx, np):
+    S = dsc.empty((4096, 32769), dsc.Dtype.C32)
+    o = dsc.empty((1, 32769), dsc.Dtype.C32)
+    return (lambda: B.dsc_sum(ctx, S._c_ptr, o._c_ptr, 0, True)), 4096 * 32769 * 8, (S, o)
+
+
+@case('sum_c32_axis1')
+def _sum1(dsc, B, ctx, np):
+    S = dsc.empty((4096, 32769), dsc.Dtype.C32)
+    o = dsc.empty((4096, 1), dsc.Dtype.C32)
+    return (lambda: B.dsc_sum(ctx, S._c_ptr, o._c_ptr, 1, True)), 4096 * 32769 * 8, (S, o)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('case', nargs='?')
+    ap.add_argument('--iters', type=int, default=30)
+    ap.add_argument('--list', action='store_true')
+    args = ap.parse_args()
+    if args.list:
+        print(' '.join(CASES))
+        return
+    fd = os.dup(1)
+    os.dup2(2, 1)
+    import numpy as np
+    import dsc_amd as dsc
+    from dsc_amd import _bindings as B
+    from dsc_amd.context import _get_ctx
+    dsc.init(20 << 30, 6 << 30)
+    ctx = _get_ctx()
+    f, nbytes, keep = CASES[args.case](dsc, B, ctx, np)
+    for _ in range(max(5, args.iters // 3)):
+        f()
+    dsc.synchronize()
+    best = 1e30
+    for _ in range(3):
+        B.dsc_timer_start(ctx)
+        for _ in range(args.iters):
+            f()
+        best = min(best, B.dsc_timer_stop(ctx) / args.iters)
+    path = dsc.last_fft_path()
+    sys.stdout.flush()
+    os.dup2(fd, 1)
+    print(json.dumps({'case': args.case, 'algorithmic_bytes': nbytes, 'hip_event_ms': round(best, 4), 'path': path,
+                      'frac_of_8TBps': round(nbytes / best / 1e6 / 8000, 4)}), flush=True)
+
+
+if __name__ == '__main__':
+    main()
