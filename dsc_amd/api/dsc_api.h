@@ -2,7 +2,7 @@
 //
 // Mirror of the reference's dsc/api/dsc_api.h for the hot-path subset: `dsc::init`, RAII
 // `dsc::tensor<T>`, `operator*`, `dsc::sum`, `dsc::fft / ifft / rfft / irfft` (reference
-// lines 15-21, 24-34, 36-143, 165-173, 285-290, 321-343) plus `dsc::filter_fft`.  The one semantic
+// lines 15-21, 24-34, 36-143, 148-186, 285-302, 321-343) plus `dsc::filter_fft`.  The one semantic
 // difference: tensor payloads live in HBM, so construction from host data and `to_host()`
 // copy through dsc_copy_from_host / dsc_copy_to_host instead of dereferencing `data()`
 // (reference: memcpy into x_->data, dsc_api.h:63-66).
@@ -63,8 +63,27 @@ public:
         x_ = dsc_new_tensor(ctx, n, s, dtype_of<T>::value, nullptr);
         dsc_copy_from_host(ctx, x_, host, ne * sizeof(T));
     }
-    tensor(const tensor &) = delete;
-    tensor &operator=(const tensor &) = delete;
+    // {a, b, c} -> 1-D tensor of scalars; ({shape}, fill) -> constant tensor        (dsc_api.h:46-57)
+    tensor(std::initializer_list<T> scalars) noexcept : tensor(std::vector<T>(scalars).data(), (int) scalars.size()) {}
+    tensor(std::initializer_list<int> shape, const T fill) noexcept {
+        int s[DSC_MAX_DIMS];
+        int n = 0;
+        size_t ne = 1;
+        for (int d : shape) { s[n++] = d; ne *= (size_t) d; }
+        x_ = dsc_new_tensor(ctx, n, s, dtype_of<T>::value, nullptr);
+        const std::vector<T> host(ne, fill);
+        dsc_copy_from_host(ctx, x_, host.data(), ne * sizeof(T));
+    }
+    // Copies are DEEP, as in the reference (memcpy of the payload, dsc_api.h:63-81); here the payload is copied on the
+    // device: selecting everything with one full slice is dsc_tensor_get_slice's copy kernel.
+    tensor(const tensor &o) noexcept : x_(o.x_ == nullptr ? nullptr : clone(o.x_)) {}
+    tensor &operator=(const tensor &o) noexcept {
+        if (this != &o) {
+            if (x_ != nullptr) dsc_tensor_free(ctx, x_);
+            x_ = o.x_ == nullptr ? nullptr : clone(o.x_);
+        }
+        return *this;
+    }
     tensor(tensor &&o) noexcept : x_(o.x_) { o.x_ = nullptr; }
     tensor &operator=(tensor &&o) noexcept {
         if (this != &o) {
@@ -93,7 +112,22 @@ public:
         return out;
     }
 
-    tensor operator*(const tensor &other) const noexcept { return dsc_mul(ctx, x_, other.x_, nullptr); }   // dsc_api.h:165-173
+    // dsc_api.h:148-186: element-wise operators with broadcasting; a scalar operand of the tensor's own element type is
+    // wrapped into a one-element tensor (dsc_wrap_*), on either side.
+    tensor operator+(const tensor &o) const noexcept { return dsc_add(ctx, x_, o.x_, nullptr); }
+    tensor operator+(const T v) const noexcept { return dsc_add(ctx, x_, wrap(v).x_, nullptr); }
+    friend tensor operator+(const T v, const tensor &o) noexcept { return wrap(v) + o; }
+    tensor operator-(const tensor &o) const noexcept { return dsc_sub(ctx, x_, o.x_, nullptr); }
+    tensor operator-(const T v) const noexcept { return dsc_sub(ctx, x_, wrap(v).x_, nullptr); }
+    friend tensor operator-(const T v, const tensor &o) noexcept { return wrap(v) - o; }
+    tensor operator*(const tensor &o) const noexcept { return dsc_mul(ctx, x_, o.x_, nullptr); }
+    tensor operator*(const T v) const noexcept { return dsc_mul(ctx, x_, wrap(v).x_, nullptr); }
+    friend tensor operator*(const T v, const tensor &o) noexcept { return wrap(v) * o; }
+    tensor operator/(const tensor &o) const noexcept { return dsc_div(ctx, x_, o.x_, nullptr); }
+    tensor operator/(const T v) const noexcept { return dsc_div(ctx, x_, wrap(v).x_, nullptr); }
+    friend tensor operator/(const T v, const tensor &o) noexcept { return wrap(v) / o; }
+    tensor &operator/=(const tensor &o) noexcept { dsc_div(ctx, x_, o.x_, x_); return *this; }     // in place: out = x
+    tensor &operator*=(const tensor &o) noexcept { dsc_mul(ctx, x_, o.x_, x_); return *this; }
 
     // dsc_api.h:117-143: x.get(2, 3) (indexes) / x.get(DSC_SLICE_ALL(), DSC_SLICE_TO(n)) (slices) copy on the device
     template<typename... Args>
@@ -109,6 +143,15 @@ public:
     }
 
     dsc_tensor *x_;
+
+private:
+    static dsc_tensor *clone(dsc_tensor *src) noexcept { return dsc_tensor_get_slice(ctx, src, 1, DSC_SLICE_ALL()); }
+    static tensor wrap(const T v) noexcept {
+        if constexpr (std::is_same_v<T, float>)        return dsc_wrap_f32(ctx, v);
+        else if constexpr (std::is_same_v<T, double>)  return dsc_wrap_f64(ctx, v);
+        else if constexpr (std::is_same_v<T, dsc_c32>) return dsc_wrap_c32(ctx, v);
+        else                                           return dsc_wrap_c64(ctx, v);
+    }
 };
 
 template<typename T>
@@ -126,6 +169,14 @@ static inline tensor<T> max(const tensor<T> &x, int axis = -1, bool keep_dims = 
 template<typename T>
 static inline tensor<T> min(const tensor<T> &x, int axis = -1, bool keep_dims = true) noexcept {
     return dsc_min(ctx, x.x_, nullptr, axis, keep_dims);
+}
+
+// dsc_api.h:294-302: transpose(x) reverses the axes, transpose(x, 1, 0, ...) permutes them
+template<typename T, typename... Args>
+static inline tensor<T> transpose(const tensor<T> &x, Args... axes) noexcept {
+    static_assert((std::is_same_v<Args, int> && ...), "axes are ints");
+    if constexpr (sizeof...(Args) == 0) return dsc_transpose(ctx, x.x_, 0);
+    else                                return dsc_transpose(ctx, x.x_, (int) sizeof...(Args), axes...);
 }
 
 template<typename T>

@@ -32,5 +32,55 @@ int main(int argc, char **argv) {
     bool crop_ok = crop.dim(-1) == 1000 && hc.size() == 1000;
     for (int i = 0; i < 1000 && crop_ok; ++i) crop_ok = hc[i] == h1[i];
     std::printf("crop %s\n", crop_ok ? "ok" : "MISMATCH");
-    return std::sqrt(diff / ref) < 1e-5 && crop_ok ? 0 : 1;
+
+    // operators of dsc/api/dsc_api.h:148-186 against host arithmetic (exact: one IEEE operation per element)
+    const int m = 6;
+    const float ha[m] = {1.5f, -2.f, 3.25f, 4.f, -5.5f, 6.f}, hb[m] = {0.5f, 4.f, -1.25f, 8.f, 2.f, -3.f};
+    dsc::tensor<float> ta(ha, {2, 3}), tbb(hb, {2, 3});
+    bool ops_ok = true;
+    auto check = [&](const dsc::tensor<float> &t, auto f, const char *what) {
+        auto h = t.to_host();
+        for (int i = 0; i < m; ++i)
+            if (h[i] != f(i)) { ops_ok = false; std::printf("operator %s: element %d is %g, want %g\n", what, i, h[i], f(i)); }
+    };
+    check(ta + tbb, [&](int i) { return ha[i] + hb[i]; }, "+");
+    check(ta - tbb, [&](int i) { return ha[i] - hb[i]; }, "-");
+    check(ta * tbb, [&](int i) { return ha[i] * hb[i]; }, "*");
+    check(ta / tbb, [&](int i) { return ha[i] / hb[i]; }, "/");
+    check(ta * 2.5f, [&](int i) { return ha[i] * 2.5f; }, "* scalar");
+    check(2.5f * ta, [&](int i) { return 2.5f * ha[i]; }, "scalar *");
+    check(ta + 1.f, [&](int i) { return ha[i] + 1.f; }, "+ scalar");
+    check(1.f - ta, [&](int i) { return 1.f - ha[i]; }, "scalar -");
+    check(ta / 4.f, [&](int i) { return ha[i] / 4.f; }, "/ scalar");
+    {
+        dsc::tensor<float> c(ta);                                    // deep copy (dsc_api.h:63-66)
+        c /= tbb;                                                     // in place (dsc_api.h:180-183)
+        check(c, [&](int i) { return ha[i] / hb[i]; }, "/=");
+        check(ta, [&](int i) { return ha[i]; }, "copy is deep");
+        dsc::tensor<float> d;
+        d = tbb;                                                      // copy assignment (dsc_api.h:74-81)
+        d /= d;
+        check(d, [&](int) { return 1.f; }, "copy-assign + /=");
+        check(tbb, [&](int i) { return hb[i]; }, "copy-assign is deep");
+    }
+    {
+        auto t = dsc::transpose(ta);                                 // dsc_api.h:294-302: [2,3] -> [3,2]
+        auto h = t.to_host();
+        bool ok = t.dim(0) == 3 && t.dim(1) == 2;
+        for (int i = 0; i < 3 && ok; ++i) for (int j = 0; j < 2; ++j) ok = ok && h[i * 2 + j] == ha[j * 3 + i];
+        auto t2 = dsc::transpose(ta, 1, 0).to_host();
+        for (int i = 0; i < m; ++i) ok = ok && t2[i] == h[i];
+        if (!ok) { ops_ok = false; std::printf("transpose MISMATCH\n"); }
+        dsc::tensor<float> filled({2, 2}, 7.f), lst{1.f, 2.f, 3.f};
+        auto hf = filled.to_host(), hl = lst.to_host();
+        if (!(hf.size() == 4 && hf[3] == 7.f && hl.size() == 3 && hl[2] == 3.f)) { ops_ok = false; std::printf("ctor MISMATCH\n"); }
+    }
+    {
+        const dsc_c32 hz[2] = {{1.f, 2.f}, {-3.f, 0.5f}};
+        dsc::tensor<dsc_c32> z(hz, 2);
+        auto hw = (z * dsc_c32{0.f, 1.f}).to_host();               // times i: (re, im) -> (-im, re)
+        if (!(hw[0].real == -2.f && hw[0].imag == 1.f && hw[1].real == -0.5f && hw[1].imag == -3.f)) { ops_ok = false; std::printf("complex scalar * MISMATCH\n"); }
+    }
+    std::printf("operators %s\n", ops_ok ? "ok" : "MISMATCH");
+    return std::sqrt(diff / ref) < 1e-5 && crop_ok && ops_ok ? 0 : 1;
 }

@@ -105,4 +105,4 @@ def test_cpp_api_filter_and_crop_on_gpu(lib, tmp_path):
     exe = _build_cpp_smoke(tmp_path)
     r = subprocess.run([exe, '1'], capture_output=True, text=True)
     assert r.returncode == 0, (r.stdout, r.stderr)
-    assert 'crop ok' in r.stdout
+    assert 'crop ok' in r.stdout and 'operators ok' in r.stdout, r.stdout

@@ -12,6 +12,23 @@ out = sys.argv[1].rstrip('/')
 KB = 1024.0
 
 
+def short_name(full):
+    """'void (anonymous namespace)::fft_mid_kernel<float, 4, ...>(args)' -> 'fft_mid_kernel<float, 4, ...>'"""
+    n = full.replace('(anonymous namespace)::', '')
+    if n.startswith('void '):
+        n = n[5:]
+    depth = 0
+    for i, ch in enumerate(n):            # cut the argument list: the first '(' outside template brackets
+        if ch == '<':
+            depth += 1
+        elif ch == '>':
+            depth -= 1
+        elif ch == '(' and depth == 0:
+            n = n[:i]
+            break
+    return n[:90]
+
+
 def cal(sub):
     vals = []
     for f in glob.glob(f'{out}/{sub}/*/*_counter_collection.csv'):
@@ -46,7 +63,7 @@ for d in sorted(glob.glob(f'{out}/*/plain.json')):
         # kernels of the timed loop: those called at least as often as the timed launches (3 x 30), set-up kernels are called once or twice
         for r in rows:
             if int(r['Calls']) >= 90:
-                kern.append((r['Name'].split('(')[0].replace('(anonymous namespace)::', '')[-60:], int(r['Calls']), float(r['AverageNs']) / 1e6))
+                kern.append((short_name(r['Name']), int(r['Calls']), float(r['AverageNs']) / 1e6))
     tot = sum(k[2] * k[1] for k in kern) / max(1, max((k[1] for k in kern), default=1))
     if kern:
         dominant[c] = max(kern, key=lambda k: k[2])[0]
@@ -62,7 +79,7 @@ for d in sorted(glob.glob(f'{out}/*/pmc1')):
     key = dominant.get(c, '')
     for f in glob.glob(f'{cdir}/pmc*/*/*_counter_collection.csv'):
         for r in csv.DictReader(open(f)):
-            if key and key.split('<')[0] not in r['Kernel_Name']:
+            if key and key.split('<')[0] not in r['Kernel_Name'].replace('(anonymous namespace)::', ''):
                 continue
             acc.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
             meta = (r['Grid_Size'], r['Workgroup_Size'], r['LDS_Block_Size'], r['VGPR_Count'], r.get('Accum_VGPR_Count', '?'), r['SGPR_Count'])
