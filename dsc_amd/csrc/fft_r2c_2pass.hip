@@ -27,6 +27,14 @@
 
 namespace {
 
+// Cache policy of the INTERMEDIATE (the work array between the two kernels): default (cached) — it is written by one kernel
+// and read back by the next, and when the launches are cut into chunks of rows it can stay in the 256 MiB Infinity Cache.
+// The external rows are touched once and stay non-temporal (kStream).
+#ifndef DSC_2PASS_WORK_POLICY
+#define DSC_2PASS_WORK_POLICY 0
+#endif
+constexpr int kWork = DSC_2PASS_WORK_POLICY;
+
 constexpr int kPQ = 1060;                    // rows kernel: plane pitch per line (values), = 4 mod 32: conflict-free both ways
 
 template<typename R> constexpr int rows_lds_bytes() { return (16 * kPQ + 2 * 1024) * (int) sizeof(R); }          // plane + W_1024
@@ -107,10 +115,10 @@ __global__ __launch_bounds__(512, (waves_per_eu<R>())) void two_pass_rows_kernel
         dft_n<R, false, 32>(v);                                               // over t -> k3 in v[brev(k3)]
         four_step_twiddle<R, false, true>(v, twL, j1r, rtau);
 #pragma unroll
-        for (int k3 = 0; k3 < 32; ++k3) buf_store<kStream>(v[brev(k3, 5)], rout, aoff, k3 * ASTEP);
+        for (int k3 = 0; k3 < 32; ++k3) buf_store<kWork>(v[brev(k3, 5)], rout, aoff, k3 * ASTEP);
     } else {
 #pragma unroll
-        for (int k3 = 0; k3 < 32; ++k3) v[k3] = buf_load<kStream>(rin, aoff, k3 * ASTEP, R{});
+        for (int k3 = 0; k3 < 32; ++k3) v[k3] = buf_load<kWork>(rin, aoff, k3 * ASTEP, R{});
         __syncthreads();
         four_step_twiddle<R, true, false>(v, twL, j1r, rtau);
         dft_n<R, true, 32>(v);                                                // over k3 -> t in v[brev(t)]
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(512, (waves_per_eu<R>())) void two_pass_cols_kernel
     C u[32], v[32];
     if constexpr (!INV) {
 #pragma unroll
-        for (int i = 0; i < 32; ++i) u[i] = buf_load<kStream>(rwork, woff, i * WSTEP, R{});
+        for (int i = 0; i < 32; ++i) u[i] = buf_load<kWork>(rwork, woff, i * WSTEP, R{});
         __syncthreads();
         dft_n<R, false, 32>(u);                                               // over i -> k' in u[brev(k')]
         if constexpr (B1 > 1) {
@@ -332,7 +340,7 @@ __global__ __launch_bounds__(512, (waves_per_eu<R>())) void two_pass_cols_kernel
         }
         dft_n<R, true, 32>(u);                                                // over k' -> i in u[brev(i)]
 #pragma unroll
-        for (int i = 0; i < 32; ++i) buf_store<kStream>(u[brev(i, 5)], rwork, woff, i * WSTEP);
+        for (int i = 0; i < 32; ++i) buf_store<kWork>(u[brev(i, 5)], rwork, woff, i * WSTEP);
     }
 }
 
