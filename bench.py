@@ -13,7 +13,10 @@ is timed as its own phase, outside the timed region, and reported beside the met
 (`allgather`), because it is xGMI-bound at >= 14 ms against ~1 ms of transform.
 
 Prints ONE JSON line on rank 0.  Extra keys beyond the driver's contract:
-  roofline      dominant kernel vs the 8 TB/s HBM peak (algorithmic bytes / HIP-event time)
+  roofline      dominant kernel vs the 8 TB/s HBM peak (algorithmic bytes / HIP-event time); `traffic` is the PMC figure
+                recorded under profiles/ for the same kernel and size (`traffic_source` says where / when; null if none)
+  other_kernels irfft, fused filter and config 5, each a full roofline object (same timer, never part of `value`)
+  allgather     the shard-reassembly phase (dsc_amd/shard.py): every method timed and verified (N > 1 only)
   cpu_baseline  the reference's own CPU code (oracle/_ref, kind "reference") or our C
                 restatement (kind "port") timed on this host, rank 0, N == 1 only
   parity        rel-L2 of a few GPU rows against the CPU oracle (checker, not timed)
@@ -91,6 +94,33 @@ def cpu_baseline(rows=1024, reps=5, warm=2):
         'sample': f'{rows} rows of the same [8192, 65536] f32 workload, min of {reps} after {warm} warm-ups, '
                   f'{best * 1e3:.1f} ms per pass, host {os.cpu_count()} logical CPUs',
     }
+
+
+def recorded_traffic(kernel, nbytes):
+    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE + WRITE_SIZE, corrected as
+    the guide prescribes) — NOT measured in this run: counters need their own profiled passes.  Returned only for the same
+    kernel at the same algorithmic size, together with where and when it was measured; otherwise (None, None)."""
+    tf = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
+    try:
+        rec = json.load(open(tf)).get('kernels', {}).get(kernel)
+        if rec and rec.get('algorithmic_bytes_per_launch') == nbytes:
+            return rec['hbm_bytes_per_launch'], {'measured_in_this_run': False, 'file': 'profiles/traffic_latest.json',
+                                                 'from': rec.get('source'), 'date': rec.get('date'), 'method': rec.get('method')}
+    except Exception:
+        pass
+    return None, None
+
+
+def roofline_object(kernel, path, nbytes, ms, rows, workload=None):
+    """The `roofline` contract: algorithmic bytes / HIP-event launch time against the 8 TB/s HBM peak."""
+    achieved = nbytes / (ms * 1e-3) / 1e9
+    traffic, source = recorded_traffic(kernel, nbytes)
+    o = {'bound': 'hbm', 'kernel': kernel, 'kernel_path': path, 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': source,
+         'algorithmic_bytes_per_launch': nbytes, 'kernel_ms': round(ms, 4), 'rows': rows}
+    if workload:
+        o['workload'] = workload
+    return o
 
 
 def gather_phase(args, dist, world, rank, rows, barrier_sync, gpu):
@@ -211,6 +241,7 @@ def main():
     ap.add_argument('--batch', type=int, default=BATCH, help='rows per GPU (default: BASELINE config 2)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-kernels', action='store_true', help='skip the untimed-for-value irfft / fused-filter measurements')
+    ap.add_argument('--no-c5', action='store_true', help='skip the config-5 (f64 N=262144) entry of other_kernels')
     ap.add_argument('--no-allgather', action='store_true')
     ap.add_argument('--allgather-timeout', type=float, default=240.0, help='seconds the separate shard-reassembly phase may take before it is abandoned (every rank then exits 3)')
     ap.add_argument('--gather-methods', default='allgather,p2p,ipc', help='exchange methods of dsc_amd/shard.py to run and verify, in this order')
@@ -260,7 +291,8 @@ def main():
             import dsc_amd as dsc
             from dsc_amd import _bindings as B
             from dsc_amd.context import _get_ctx
-            dsc.init(2 * rows * BYTES_PER_ROW + (1 << 30), 1 << 30, device=local_rank)
+            # main arena: x + out, irfft / filter buffers, config 5 (4 + 4 GiB); scratch: the two-pass intermediate in 512-row chunks
+            dsc.init(2 * rows * BYTES_PER_ROW + ((14 << 30) if not args.no_other_kernels else (1 << 30)), (2 << 30) if not args.no_other_kernels else (1 << 30), device=local_rank)
         ctx = _get_ctx()
         x_host = synthetic_rows(rows, rank)
         x = dsc.from_numpy(x_host)
@@ -303,16 +335,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- the other two kernels of the hot path on the same buffers (configs[1] irfft, configs[2] fused filter on half the
-    # batch): reported next to the metric, never part of `value`
+    # ---- the other kernels of the hot path (configs[1] irfft on the same buffers, configs[2] fused filter on half the batch,
+    # configs[4] rfft f64 N=262144): each a full roofline object, reported next to the metric, never part of `value`
     if not args.dry_run and not args.no_other_kernels:
         try:
-            back = dsc.empty((rows, N_FFT), dsc.Dtype.F32)
-            H = dsc.from_numpy(np.ones(N_FFT // 2 + 1, np.complex64))
-            half = rows // 2 if rows >= 2 else rows
-            s_half = dsc.from_numpy(x_host[:half])
-            y_half = dsc.empty((half, N_FFT), dsc.Dtype.F32)
-
             def timed(f, n=args.steps):
                 for _ in range(max(10, args.warmup)):
                     f()
@@ -322,18 +348,39 @@ def main():
                     f()
                 return B.dsc_timer_stop(ctx) / n
 
+            ok = {}
+            back = dsc.empty((rows, N_FFT), dsc.Dtype.F32)
             ms_i = timed(lambda: B.dsc_irfft(ctx, out._c_ptr, back._c_ptr, -1, -1))
-            p_i = dsc.last_fft_path()
+            ok['irfft'] = roofline_object('irfft64k_kernel', dsc.last_fft_path(), rows * BYTES_PER_ROW, ms_i, rows,
+                                          f'1-D irfft f32 N={N_FFT} batch={rows} (BASELINE configs[1]), input = the spectrum the timed rfft wrote')
+            del back
+            rngf = np.random.default_rng(7)
+            H = dsc.from_numpy((rngf.standard_normal(N_FFT // 2 + 1) + 1j * rngf.standard_normal(N_FFT // 2 + 1)).astype(np.complex64))
+            half = rows // 2 if rows >= 2 else rows
+            s_half = dsc.from_numpy(x_host[:half])
+            y_half = dsc.empty((half, N_FFT), dsc.Dtype.F32)
             ms_f = timed(lambda: B.dsc_filter_fft(ctx, s_half._c_ptr, H._c_ptr, y_half._c_ptr))
-            p_f = dsc.last_fft_path()
-            extra['other_kernels'] = {
-                'irfft': {'ms': round(ms_i, 4), 'frac_of_8TBps': round(rows * BYTES_PER_ROW / (ms_i * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                          'rows': rows, 'kernel_path': p_i},
-                'fused_filter': {'ms': round(ms_f, 4), 'frac_of_8TBps': round(half * N_FFT * 8 / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                 'rows': half, 'kernel_path': p_f, 'bytes_per_sample': 8},
-                'note': 'same process, same HIP-event timer, this rank only; not included in value',
-            }
-            del back, H, s_half, y_half
+            ok['fused_filter'] = roofline_object('filter64k_kernel', dsc.last_fft_path(), half * N_FFT * 8, ms_f, half,
+                                                 f'y = irfft(rfft(s) * H) fused, N={N_FFT} batch={half} (BASELINE configs[2]), 4 B in + 4 B out per sample, H [32769] c32 broadcast')
+            del H, s_half, y_half
+            if rows >= BATCH and not args.no_c5:
+                n5, b5 = 262144, 2048
+                x5 = dsc.empty((b5, n5), dsc.Dtype.F64)
+                X5 = dsc.empty((b5, n5 // 2 + 1), dsc.Dtype.C64)
+                blk = np.random.default_rng(99).standard_normal((64, n5))
+                import ctypes
+                shp = (ctypes.c_int * 2)(64, n5)
+                for r0 in range(0, b5, 64):               # the same 64 random rows 32 times: no 4 GiB host array
+                    piece = B.dsc_tensor_from_device_ptr(ctx, x5._c_ptr.contents.data + r0 * n5 * 8, 64 * n5 * 8, 2, shp, int(dsc.Dtype.F64))
+                    B.dsc_copy_from_host(ctx, piece, blk.ctypes.data, blk.nbytes)
+                    B.dsc_tensor_free(ctx, piece)
+                ms_5 = timed(lambda: B.dsc_rfft(ctx, x5._c_ptr, X5._c_ptr, -1, -1), n=20)
+                ok['rfft_f64_262144'] = roofline_object('two_pass_rows_kernel + two_pass_cols_kernel', dsc.last_fft_path(),
+                                                        b5 * (n5 * 8 + (n5 // 2 + 1) * 16), ms_5, b5,
+                                                        f'1-D rfft f64 N={n5} batch={b5} (BASELINE configs[4]); two kernels, the time is their sum')
+                del x5, X5
+            ok['note'] = 'same process, same HIP-event timer, this rank only, random inputs; not included in value'
+            extra['other_kernels'] = ok
         except Exception as e:
             extra['other_kernels'] = {'error': repr(e)[:200]}
 
@@ -359,25 +406,7 @@ def main():
                        'kernel_path': path, 'clock_ramp_ms_untimed': 0.0 if args.dry_run else args.ramp_ms},
         }
         if not args.dry_run:
-            achieved = rows * BYTES_PER_ROW / (kernel_ms * 1e-3) / 1e9
-            traffic = None
-            tf = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
-            if os.path.exists(tf):
-                try:
-                    traffic = json.load(open(tf)).get('hbm_bytes_per_launch')
-                except Exception:
-                    traffic = None
-            line['roofline'] = {
-                'bound': 'hbm',
-                'kernel': 'rfft64k_kernel' if path == 'r2c_64k_regs' else path,
-                'achieved': round(achieved, 1),
-                'peak': HBM_PEAK_GBS,
-                'unit': 'GB/s',
-                'frac': round(achieved / HBM_PEAK_GBS, 4),
-                'traffic': traffic,
-                'algorithmic_bytes_per_launch': rows * BYTES_PER_ROW,
-                'kernel_ms': round(kernel_ms, 4),
-            }
+            line['roofline'] = roofline_object('rfft64k_kernel' if path == 'r2c_64k_regs' else path, path, rows * BYTES_PER_ROW, kernel_ms, rows)
             line['parity'] = {'rel_l2_vs_cpu_oracle': parity, 'rows_checked': 4, 'tolerance': 1e-5}
             if world == 1 and not args.no_cpu_baseline:
                 line['cpu_baseline'] = cpu_baseline()

@@ -23,6 +23,21 @@ void dsc_main_arena::clear() {
 // from_top: carve the block from the END of the highest free block that fits.  Used for the long-lived FFT plan
 // tables: placed by best fit they end up wherever a tensor happened to be freed and cut the space for large tensors in
 // two (a [2048, 262144] f64 batch needs three contiguous 4 GiB blocks); kept at the top they stay out of the way.
+// Would blocks of these sizes (0 = unused) fit next to each other right now?  For callers that have another way when the
+// arena is tight (the reference's allocator can only exit, dsc_allocator.cpp:112-114).  Exact for up to two blocks: each
+// goes into its own free block, or both into one that holds their sum.
+bool dsc_main_arena::fits(size_t nb_a, size_t nb_b) const {
+    const size_t a = nb_a ? DSC_ALIGN_UP(nb_a, DSC_DEVICE_ALIGN) : 0, b = nb_b ? DSC_ALIGN_UP(nb_b, DSC_DEVICE_ALIGN) : 0;
+    const size_t hi = a > b ? a : b, lo = a > b ? b : a;
+    int n_hi = 0, n_lo = 0;
+    for (const auto &blk : free_) {
+        if (blk.second >= a + b) return true;
+        if (blk.second >= hi) ++n_hi;
+        else if (blk.second >= lo) ++n_lo;
+    }
+    return n_hi >= 2 || (n_hi >= 1 && n_lo >= 1) || (lo == 0 && n_hi >= 1);
+}
+
 char *dsc_main_arena::alloc(size_t nb, bool from_top) {
     DSC_ASSERT(nb > 0);
     const size_t need = DSC_ALIGN_UP(nb, DSC_DEVICE_ALIGN);

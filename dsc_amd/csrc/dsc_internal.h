@@ -78,6 +78,7 @@ class dsc_main_arena {
 public:
     void init(char *base, size_t size);
     char *alloc(size_t nb, bool from_top = false);   // fatal when no block fits (dsc_allocator.cpp:112-114)
+    bool fits(size_t nb_a, size_t nb_b = 0) const;   // non-fatal probe: would these two blocks fit now?
     void free(char *p);                  // unknown / already freed pointers are ignored (:152-181)
     void clear();
     size_t used() const { return used_; }

@@ -256,7 +256,10 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
          (sp && packed && j.L == 32768))) {
         const int x_n = j.x->shape[j.slot], out_n = j.out->shape[j.slot];
         const long long outer = n_lines / inner;
-        if (outer * inner < (1LL << 31)) {
+        // the route needs two full-size temporaries in the main arena; a context sized for x and out only keeps the strided
+        // LDS kernel below (the reference needs two line-sized scratch buffers for the same call, dsc.cpp:2115-2116)
+        const bool room = ctx->main.fits((size_t) j.x->ne * dsc_dtype_size(j.x->dtype), (size_t) j.out->ne * dsc_dtype_size(j.out->dtype));
+        if (outer * inner < (1LL << 31) && room) {
             const int shape_in[2] = {(int) (outer * inner), x_n}, shape_out[2] = {(int) (outer * inner), out_n};
             dsc_tensor *t_in = dsc_new_tensor(ctx, 2, shape_in, j.x->dtype, nullptr);
             dsc_tensor *t_out = dsc_new_tensor(ctx, 2, shape_out, j.out->dtype, nullptr);

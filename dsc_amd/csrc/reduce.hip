@@ -13,9 +13,16 @@
 //               strided partial accumulators per thread, then a wave shuffle + LDS tree.
 //               Sum order differs from the reference here (tolerance in the tests).
 //
-// max/min select an element, so they are exact either way; ties follow the reference:
-// complex compares the real part only, max keeps the LATER element on ties
-// (`xa.real > xb.real ? xa : xb`), complex min the EARLIER one, real min the later one.
+// max/min select an element, so they are exact either way — including ties and NaNs, which follow
+// from the reference's predicates applied left to right (dsc_ops.h:318-339, dsc.h:43-44):
+//   max        acc = acc > x ? acc : x          complex: .real only; ties -> the LATER element
+//   min real   acc = acc < x ? acc : x          ties -> the later element
+//   min cplx   acc = acc.real > x.real ? x : acc   ties -> the EARLIER element
+// A NaN compares false: max and the real min TAKE a NaN x and then drop it again at the next element,
+// so the result is the max / min of the elements AFTER the last NaN (the NaN itself if it is last);
+// the complex min never takes one.  The sequential kernels apply the predicate as is; partial results
+// carry "contains a NaN", which makes the ordered combination exact (a segment with a NaN wipes what
+// came before it); the tree kernel finds the last NaN of the row first.
 #include "kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -34,7 +41,22 @@ __device__ __forceinline__ acc_t<R, CPLX> acc_init() {
     return {(R) 0, (R) 0, -1};
 }
 
-// combine(a, b): a precedes b along the axis unless idx says otherwise
+// The reference's step acc <- op(acc, x), x the NEXT element along the axis (a partial result of a later segment when
+// called from the ordered combination).  acc.idx doubles as "this partial contains a NaN" (max, real min).
+template<int OP, bool CPLX> constexpr bool nan_wipes() { return OP == 2 || (OP == 3 && !CPLX); }
+template<typename R, bool CPLX, int OP>
+__device__ __forceinline__ acc_t<R, CPLX> step(acc_t<R, CPLX> acc, acc_t<R, CPLX> x) {
+    bool take_x;
+    if (OP == 2)    take_x = !(acc.r > x.r);
+    else if (!CPLX) take_x = !(acc.r < x.r);
+    else            take_x = acc.r > x.r;
+    if (nan_wipes<OP, CPLX>() && x.idx > 0) take_x = true;            // x is a partial that saw a NaN: it decides alone
+    acc_t<R, CPLX> o = take_x ? x : acc;
+    o.idx = (acc.idx > 0 || x.idx > 0 || (nan_wipes<OP, CPLX>() && x.r != x.r)) ? 1 : 0;
+    return o;
+}
+
+// combine(a, b) for the tree kernel: order-free by position (idx), NaN-free inputs only
 template<typename R, bool CPLX, int OP>
 __device__ __forceinline__ acc_t<R, CPLX> combine(acc_t<R, CPLX> a, acc_t<R, CPLX> b) {
     if (OP <= 1) return {a.r + b.r, a.i + b.i, 0};
@@ -73,10 +95,11 @@ __global__ void reduce_seq_kernel(const void *x, void *out, long long outer, int
         const long long oo = o / inner, ii = o - oo * inner;
         const long long base = oo * axis_n * inner + ii;
         acc_t<R, CPLX> acc = acc_init<R, CPLX, OP>();
+        acc.idx = 0;
         for (int j = 0; j < axis_n; ++j) {
-            const acc_t<R, CPLX> v = load_elem<R, CPLX>(x, base + (long long) j * inner, j);
+            const acc_t<R, CPLX> v = load_elem<R, CPLX>(x, base + (long long) j * inner, 0);
             if (OP <= 1) { acc.r = acc.r + v.r; acc.i = acc.i + v.i; }
-            else acc = combine<R, CPLX, OP>(acc, v);
+            else acc = step<R, CPLX, OP>(acc, v);
         }
         store_elem<R, CPLX, OP>(out, o, acc, axis_n);
     }
@@ -96,11 +119,12 @@ __global__ void reduce_seg_kernel(const void *x, R *part_r, R *part_i, int *part
         const long long oo = o / inner, ii = o - oo * inner;
         const long long base = oo * axis_n * inner + ii;
         acc_t<R, CPLX> acc = acc_init<R, CPLX, OP>();
+        acc.idx = 0;
 #pragma unroll 4
         for (int j = j0; j < j1; ++j) {
-            const acc_t<R, CPLX> v = load_elem<R, CPLX>(x, base + (long long) j * inner, j);
+            const acc_t<R, CPLX> v = load_elem<R, CPLX>(x, base + (long long) j * inner, 0);
             if (OP <= 1) { acc.r = acc.r + v.r; acc.i = acc.i + v.i; }
-            else acc = combine<R, CPLX, OP>(acc, v);
+            else acc = step<R, CPLX, OP>(acc, v);
         }
         const long long at = (long long) seg * n_out + o;
         part_r[at] = acc.r;
@@ -114,11 +138,12 @@ __global__ void reduce_combine_kernel(const R *part_r, const R *part_i, const in
                                       int n_seg, int axis_n) {
     for (long long o = (long long) blockIdx.x * blockDim.x + threadIdx.x; o < n_out; o += (long long) gridDim.x * blockDim.x) {
         acc_t<R, CPLX> acc = acc_init<R, CPLX, OP>();
+        acc.idx = 0;
         for (int s = 0; s < n_seg; ++s) {
             const long long at = (long long) s * n_out + o;
-            acc_t<R, CPLX> v = {part_r[at], CPLX ? part_i[at] : (R) 0, OP >= 2 ? part_idx[at] : 0};
+            acc_t<R, CPLX> v = {part_r[at], CPLX ? part_i[at] : (R) 0, OP >= 2 ? part_idx[at] : 0};      // idx = the segment saw a NaN
             if (OP <= 1) { acc.r = acc.r + v.r; acc.i = acc.i + v.i; }
-            else acc = combine<R, CPLX, OP>(acc, v);
+            else acc = step<R, CPLX, OP>(acc, v);
         }
         store_elem<R, CPLX, OP>(out, o, acc, axis_n);
     }
@@ -133,22 +158,47 @@ __device__ __forceinline__ acc_t<R, CPLX> shfl_down_acc(acc_t<R, CPLX> a, int de
     return b;
 }
 
-// one 256-thread workgroup per output row (inner == 1)
+// one 256-thread workgroup per output row (inner == 1).  max / min: the threads' strided partial results are combined by
+// position (idx), which is only the reference's left-to-right result when no NaN is involved; NaNs are therefore kept out of
+// the candidates and their last position p is found alongside — the row's answer is then the max / min over j > p (a second
+// sweep, rows with a NaN only), or element p itself when p is the last element.  The complex min simply skips NaNs.
+template<typename R, bool CPLX, int OP>
+__device__ __forceinline__ acc_t<R, CPLX> block_combine(acc_t<R, CPLX> acc, acc_t<R, CPLX> (&part)[4]) {
+    for (int d = 32; d > 0; d >>= 1) acc = combine<R, CPLX, OP>(acc, shfl_down_acc<R, CPLX>(acc, d));
+    __syncthreads();                                       // part[] may still be read from the previous use
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    return combine<R, CPLX, OP>(combine<R, CPLX, OP>(part[0], part[1]), combine<R, CPLX, OP>(part[2], part[3]));
+}
+
 template<typename R, bool CPLX, int OP>
 __global__ __launch_bounds__(256) void reduce_row_kernel(const void *x, void *out, long long outer, int axis_n) {
     __shared__ acc_t<R, CPLX> part[4];
+    __shared__ int last_nan_s[4];
     for (long long row = blockIdx.x; row < outer; row += gridDim.x) {
         const long long base = row * axis_n;
         acc_t<R, CPLX> acc = acc_init<R, CPLX, OP>();
-        for (int j = threadIdx.x; j < axis_n; j += 256)
-            acc = combine<R, CPLX, OP>(acc, load_elem<R, CPLX>(x, base + j, j));
-        for (int d = 32; d > 0; d >>= 1) acc = combine<R, CPLX, OP>(acc, shfl_down_acc<R, CPLX>(acc, d));
-        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            acc = combine<R, CPLX, OP>(combine<R, CPLX, OP>(part[0], part[1]), combine<R, CPLX, OP>(part[2], part[3]));
-            store_elem<R, CPLX, OP>(out, row, acc, axis_n);
+        int last_nan = -1;
+        for (int j = threadIdx.x; j < axis_n; j += 256) {
+            const acc_t<R, CPLX> v = load_elem<R, CPLX>(x, base + j, j);
+            if (OP >= 2 && v.r != v.r) last_nan = j;       // j ascends: the thread's last NaN
+            else acc = combine<R, CPLX, OP>(acc, v);
         }
+        acc = block_combine<R, CPLX, OP>(acc, part);
+        if (OP >= 2 && nan_wipes<OP, CPLX>()) {
+            for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_down(last_nan, d, 64); last_nan = o > last_nan ? o : last_nan; }
+            if ((threadIdx.x & 63) == 0) last_nan_s[threadIdx.x >> 6] = last_nan;
+            __syncthreads();
+            int p = last_nan_s[0];
+            for (int w = 1; w < 4; ++w) p = last_nan_s[w] > p ? last_nan_s[w] : p;
+            if (p >= 0) {                                   // the reference's accumulator forgot everything up to the last NaN
+                acc = acc_init<R, CPLX, OP>();
+                for (int j = p + 1 + threadIdx.x; j < axis_n; j += 256) acc = combine<R, CPLX, OP>(acc, load_elem<R, CPLX>(x, base + j, j));
+                acc = block_combine<R, CPLX, OP>(acc, part);
+                if (p == axis_n - 1) acc = load_elem<R, CPLX>(x, base + p, p);
+            }
+        }
+        if (threadIdx.x == 0) store_elem<R, CPLX, OP>(out, row, acc, axis_n);
         __syncthreads();
     }
 }

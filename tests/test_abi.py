@@ -106,3 +106,17 @@ def test_cpp_api_filter_and_crop_on_gpu(lib, tmp_path):
     r = subprocess.run([exe, '1'], capture_output=True, text=True)
     assert r.returncode == 0, (r.stdout, r.stderr)
     assert 'crop ok' in r.stdout and 'operators ok' in r.stdout, r.stdout
+
+
+def test_reference_bindings_resolve_against_the_library(lib):
+    """INTEGRATION.md says the reference's ctypes bindings bind this library for the hot path: every name they look up for
+    that subset (a committed list of names, tests/golden/reference_binding_symbols.txt) must resolve; the rest of the
+    reference's names are exactly SURVEY section 2's OUT-OF-SCOPE set."""
+    rows = [ln.split() for ln in open(os.path.join(ROOT, 'tests', 'golden', 'reference_binding_symbols.txt')) if ln.strip() and not ln.startswith('#')]
+    assert len(rows) == 59
+    missing = [n for n, scope in rows if scope == 'path' and not hasattr(lib, n)]
+    assert not missing, missing
+    assert sum(1 for _, scope in rows if scope == 'path') == 44
+    out = sorted(n for n, scope in rows if scope == 'out')
+    assert out == ['dsc_arange', 'dsc_clip', 'dsc_concat', 'dsc_cos', 'dsc_exp', 'dsc_i0', 'dsc_log10', 'dsc_log2', 'dsc_logn', 'dsc_pow',
+                   'dsc_randn', 'dsc_reshape', 'dsc_sin', 'dsc_sinc', 'dsc_sqrt']

@@ -127,3 +127,23 @@ def test_indexing_random_keys():
         assert np.array_equal(R.set_slice(x, v, *key), want_set), (shape, key, v.shape)
         n_ok += 1
     assert n_ok > 60
+
+
+def test_max_min_with_nans_restatement_equals_reference():
+    """NaN behaviour of max / min follows from the reference's predicates (dsc_ops.h:318-339, dsc.h:43-44): the restatement
+    must reproduce it exactly, since the GPU tests use it as the oracle for NaN inputs (tests/test_gpu_lifecycle.py)."""
+    R = ref.Ref.get()
+    rng = np.random.default_rng(21)
+    for dt in (np.float32, np.float64, np.complex64, np.complex128):
+        x = rng.standard_normal((5, 7, 9))
+        if np.dtype(dt).kind == 'c':
+            x = x + 1j * rng.standard_normal((5, 7, 9))
+        x = x.astype(dt)
+        flat = x.reshape(-1)
+        flat[rng.choice(flat.size, 40, replace=False)] = np.nan
+        x[:, 3, 4] = np.nan                       # an all-NaN line along axis 0
+        x[2, :, -1] = np.nan                      # NaN as the last element along axis 2
+        for op in (port.MAX, port.MIN):
+            for axis in (0, 1, 2):
+                a, b = port.reduce(x, op, axis), R.reduce(x, op, axis)
+                assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.nan_to_num(a, nan=0.0), np.nan_to_num(b, nan=0.0)), (dt, op, axis)

@@ -7,6 +7,7 @@ import glob
 import json
 import os
 import sys
+import time
 
 out = sys.argv[1].rstrip('/')
 KB = 1024.0
@@ -71,6 +72,7 @@ for d in sorted(glob.glob(f'{out}/*/plain.json')):
     pct = j['algorithmic_bytes'] / tot / 1e6 / 80 if tot else 0
     print(f"| {c} | {j['path']} | {j['hip_event_ms']:.4f} | {j['frac_of_8TBps'] * 100:.1f} | {ktxt} | {tot:.4f} | {pct:.1f} |")
 print()
+traffic = {}
 for d in sorted(glob.glob(f'{out}/*/pmc1')):
     cdir = os.path.dirname(d)
     c = os.path.basename(cdir)
@@ -97,6 +99,9 @@ for d in sorted(glob.glob(f'{out}/*/pmc1')):
         wb = sum(acc['WRITE_SIZE']) / len(acc['WRITE_SIZE']) * KB * w_corr
         alg = j['algorithmic_bytes']
         print(f'\nHBM bytes per launch: fetch {fb / 1e9:.4f} GB + write {wb / 1e9:.4f} GB = {(fb + wb) / 1e9:.4f} GB vs algorithmic {alg / 1e9:.4f} GB: x{(fb + wb) / alg:.3f}')
+        traffic[key.split('<')[0]] = {'hbm_bytes_per_launch': fb + wb, 'algorithmic_bytes_per_launch': alg, 'ratio': round((fb + wb) / alg, 4),
+                                      'source': f'{out}/{c} (tools/profile_families.sh)', 'date': time.strftime('%Y-%m-%d'),
+                                      'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected x%.4f / x%.4f on tools/calib_copy.hip' % (f_corr, w_corr)}
     if 'SQ_WAVE_CYCLES' in acc:
         wc = sum(acc['SQ_WAVE_CYCLES']) / len(acc['SQ_WAVE_CYCLES'])
         parts = []
@@ -107,3 +112,6 @@ for d in sorted(glob.glob(f'{out}/*/pmc1')):
     if 'SQ_LDS_BANK_CONFLICT' in acc and 'SQ_LDS_IDX_ACTIVE' in acc:
         print(f"\nLDS bank-conflict cycles / LDS active cycles: {sum(acc['SQ_LDS_BANK_CONFLICT']) / max(1.0, sum(acc['SQ_LDS_IDX_ACTIVE'])) * 100:.1f} %")
     print()
+
+if traffic:
+    json.dump({'kernels': traffic}, open(f'{out}/traffic.json', 'w'), indent=1)
