@@ -214,6 +214,13 @@ constexpr int kStream = DSC_STREAM_AUX;
 __device__ __forceinline__ cf load_c(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return to_cf(__builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, kStream)));
 }
+// spectrum rows of the inverse kernel (skewed by 8 B x row; see irfft64k_kernel): policy chosen by measurement
+#ifndef DSC_IRFFT_LOAD_AUX
+#define DSC_IRFFT_LOAD_AUX 0
+#endif
+__device__ __forceinline__ cf load_c_spec(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return to_cf(__builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, DSC_IRFFT_LOAD_AUX)));
+}
 __device__ __forceinline__ cf load_c_cached(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return to_cf(__builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0)));
 }
@@ -558,10 +565,10 @@ __global__ __launch_bounds__(1024) void irfft64k_kernel(const f2 *__restrict__ X
         const int pv = (kM - c - 15 * 1024) * 8;                                     // Y[M - c - 1024 a] = pv + (15 - a) * 8192
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
-            v[a] = load_c_cached(r0, c * 8, a * 8192);
-            v[16 + a] = load_c_cached(r0, pv, (15 - a) * 8192);
+            v[a] = load_c_spec(r0, c * 8, a * 8192);
+            v[16 + a] = load_c_spec(r0, pv, (15 - a) * 8192);
         }
-        if (c == 0) y_mid = load_c_cached(r0, (kM / 2) * 8, 0);
+        if (c == 0) y_mid = load_c_spec(r0, (kM / 2) * 8, 0);
     }
 
     for (int row = blockIdx.x; row < batch; row += gridDim.x) {
@@ -581,17 +588,17 @@ __global__ __launch_bounds__(1024) void irfft64k_kernel(const f2 *__restrict__ X
             // consumption order of the pre-pass: pairs 0..7 (and bin M/2) into the even registers, pairs 8..15 into the odd ones
             if (first_half) {
                 y_mid = cf{0.f, 0.f};
-                if (c == 0) y_mid = load_c_cached(rnext, (kM / 2) * 8, 0);
+                if (c == 0) y_mid = load_c_spec(rnext, (kM / 2) * 8, 0);
 #pragma unroll
                 for (int a = 0; a < 8; ++a) {
-                    v[2 * a] = load_c_cached(rnext, c * 8, a * 8192);
-                    v[16 + 2 * a] = load_c_cached(rnext, pv, (15 - a) * 8192);
+                    v[2 * a] = load_c_spec(rnext, c * 8, a * 8192);
+                    v[16 + 2 * a] = load_c_spec(rnext, pv, (15 - a) * 8192);
                 }
             } else {
 #pragma unroll
                 for (int a = 8; a < 16; ++a) {
-                    v[2 * (a - 8) + 1] = load_c_cached(rnext, c * 8, a * 8192);
-                    v[17 + 2 * (a - 8)] = load_c_cached(rnext, pv, (15 - a) * 8192);
+                    v[2 * (a - 8) + 1] = load_c_spec(rnext, c * 8, a * 8192);
+                    v[17 + 2 * (a - 8)] = load_c_spec(rnext, pv, (15 - a) * 8192);
                 }
             }
         });

@@ -1,0 +1,358 @@
+// fft_regs_cols.hip — register-resident transforms along a NON-LAST axis (strided lines), one HBM round trip.
+//
+// Reference: the same exec_fft / exec_rfft loops (dsc/src/dsc.cpp:1958-2007, 2102-2171) — dsc_axis_iterator walks any axis
+// (dsc_iter.h:11-65), so `dsc.fft(x, axis=0)` is the same call as along the last axis (python/tests/test_ops.py:466-468).
+//
+// A tensor [outer][len][inner] transformed along `len`: element e of line (o, i) sits at ((o len + e) inner + i), i.e. the
+// lines are strided but NEIGHBOURING LINES ARE CONTIGUOUS.  So the lanes of a wave are neighbouring lines ("columns"): a
+// workgroup owns CW adjacent columns x T threads per column, thread (t, c) holds 32 elements of column c in registers —
+// every global access of a wave is CW contiguous elements (128-512 B) per row, and every LDS exchange is indexed
+// [...][c] with c fastest, which is bank-conflict free by construction.  The arithmetic is that of fft_regs_mid.hip:
+//
+//   three passes  L = 1024 B:  j = T j1 + B j2 + j3, T = 32 B threads per column:  dft32 (j1) . W_1024 . xchg . dft32 (j2) . W_L W_32B . xchg . dft_B (j3)
+//   two passes    L = 32 B:    j = B j1 + j3,        T = B:                          dft32 (j1) . W_L . xchg . dft_B (j3)
+//
+// with the packed-real pre / post pass (dsc_fft.h:194-228) through an LDS staging plane [k][c].  This replaces
+// transpose -> last-axis kernel -> transpose (three passes over HBM, 16-22 % of the roofline) for complex lengths 128 .. 4096.
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <utility>
+
+#include "fft_regs_common.h"
+
+namespace {
+
+__device__ __forceinline__ void store_real(float a, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, a), r, voff, soff, kStream);
+}
+__device__ __forceinline__ void store_real(double a, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, a), r, voff, soff, kStream);
+}
+
+template<typename R, int B, bool TWO, int CW> struct cols_cfg {
+    static constexpr int T = TWO ? B : 32 * B;         // threads per column
+    static constexpr int L = 32 * T;                   // complex length
+    static constexpr int NT = CW * T;
+    static constexpr int COLS = TWO ? 32 : 1024;       // spectrum columns entering the last pass
+    static constexpr int CPT = 32 / B;
+    static constexpr int PLANE = (L + 1) * CW;         // values: every exchange needs L per column, the real staging L + 1
+    static constexpr int TABLE = TWO ? L : 1024;       // W_L^m (two-pass) or W_1024^m
+    static constexpr int TABLE_STRIDE = TWO ? 1 : B;
+    static constexpr int WAVES_PER_EU = NT >= 1024 ? 4 : sizeof(R) == 8 ? 2 : NT >= 512 ? 4 : 2;
+};
+template<typename R, int B, bool TWO, int CW>
+constexpr size_t cols_lds_bytes() { return ((size_t) cols_cfg<R, B, TWO, CW>::PLANE + 2 * cols_cfg<R, B, TWO, CW>::TABLE) * sizeof(R); }
+
+// In: v[j1] = z[T j1 + t] of column c.  Out: v[i B + p] = bin (t + T i) + COLS brev(p).  LDS index = (flat index) * CW + c.
+template<typename R, int B, bool TWO, int CW, bool INV>
+__device__ __forceinline__ void cols_passes(cpx<R> (&v)[32], R *plane, const cpx<R> *wtab, const cpx<R> *__restrict__ tw_full, int t, int c) {
+    using C = cpx<R>;
+    using cfg = cols_cfg<R, B, TWO, CW>;
+    constexpr int T = cfg::T, CPT = cfg::CPT;
+    const int hi = TWO ? 0 : t / B, lo = TWO ? t : t % B;
+    C u[32];
+    if constexpr (!TWO) {
+        dft_n<R, INV, 32>(v);                                       // pass 1 over j1, twiddle W_1024^{j2 k1}
+#pragma unroll
+        for (int k1 = 1; k1 < 32; ++k1) {
+            const C w = wtab[hi * k1];
+            v[brev(k1, 5)] = INV ? cmulc(v[brev(k1, 5)], w) : cmul(v[brev(k1, 5)], w);
+        }
+        // exchange 1: (j2, j3)[k1] -> thread B k1 + j3, [j2]:  flat = (B k1 + j3) 32 + j2
+        R *wr = plane + (lo * 32 + hi) * CW + c;
+        const R *rd = plane + (t * 32) * CW + c;
+#pragma unroll
+        for (int k1 = 0; k1 < 32; ++k1) wr[k1 * B * 32 * CW] = v[brev(k1, 5)].x;
+        lds_barrier();
+#pragma unroll
+        for (int m = 0; m < 32; ++m) u[m].x = rd[m * CW];
+        lds_barrier();
+#pragma unroll
+        for (int k1 = 0; k1 < 32; ++k1) wr[k1 * B * 32 * CW] = v[brev(k1, 5)].y;
+        lds_barrier();
+#pragma unroll
+        for (int m = 0; m < 32; ++m) u[m].y = rd[m * CW];
+        lds_barrier();
+    } else {
+#pragma unroll
+        for (int m = 0; m < 32; ++m) u[m] = v[m];
+    }
+    dft_n<R, INV, 32>(u);                                           // pass 2 over j2 (two-pass: over j1)
+    if constexpr (TWO && B == 1) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v[k] = u[brev(k, 5)];
+        return;
+    }
+    if constexpr (!TWO) {
+        const C tw2_base = tw_full[hi * lo];                        // W_L^{j3 k1}
+        u[0] = INV ? cmulc(u[0], tw2_base) : cmul(u[0], tw2_base);
+#pragma unroll
+        for (int k2 = 1; k2 < 32; ++k2) {
+            const C w = cmul(tw2_base, wtab[(32 / B) * lo * k2]);    // x W_32B^{j3 k2}
+            u[brev(k2, 5)] = INV ? cmulc(u[brev(k2, 5)], w) : cmul(u[brev(k2, 5)], w);
+        }
+    } else {
+#pragma unroll
+        for (int k2 = 1; k2 < 32; ++k2) {
+            const C w = wtab[lo * k2];                               // W_L^{j3 k2}
+            u[brev(k2, 5)] = INV ? cmulc(u[brev(k2, 5)], w) : cmul(u[brev(k2, 5)], w);
+        }
+    }
+    // last exchange: flat = (column k') B + j3, k' = k1 + 32 k2 (two-pass: k2); thread t reads columns t + T i
+    constexpr int CS = TWO ? 1 : 32;
+    R *wr = plane + (hi * B + lo) * CW + c;
+    const R *rd = plane + (t * B) * CW + c;
+#pragma unroll
+    for (int k2 = 0; k2 < 32; ++k2) wr[k2 * CS * B * CW] = u[brev(k2, 5)].x;
+    lds_barrier();
+#pragma unroll
+    for (int i = 0; i < CPT; ++i)
+#pragma unroll
+        for (int m = 0; m < B; ++m) v[i * B + m].x = rd[(i * T * B + m) * CW];
+    lds_barrier();
+#pragma unroll
+    for (int k2 = 0; k2 < 32; ++k2) wr[k2 * CS * B * CW] = u[brev(k2, 5)].y;
+    lds_barrier();
+#pragma unroll
+    for (int i = 0; i < CPT; ++i)
+#pragma unroll
+        for (int m = 0; m < B; ++m) v[i * B + m].y = rd[(i * T * B + m) * CW];
+    lds_barrier();
+    dft_columns<R, INV, B>(v, std::make_integer_sequence<int, CPT>{});
+}
+
+// MODE: DSC_MODE_C2C (INV either way), DSC_MODE_R2C_PACKED (forward), DSC_MODE_C2R_PACKED (inverse).
+// in / out: tensor base; the transformed axis has in_len valid input elements (reals for R2C_PACKED, bins for C2R, complex
+// otherwise; the rest of the transform length reads as zero: dsc.cpp:1990-1998, 2125-2133, 2149-2157) and a pitch of `inner`
+// elements between consecutive elements; in_axis / out_axis = the axis lengths of the two tensors (slice pitch = axis * inner).
+template<typename R, int B, bool TWO, int CW, int MODE, bool INV>
+__global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO, CW>::WAVES_PER_EU)) void fft_cols_kernel(
+    const void *__restrict__ in, void *__restrict__ out, int inner, int tiles_per_slice, int in_axis, int in_len, int out_axis,
+    const cpx<R> *__restrict__ tw_full, const cpx<R> *__restrict__ tw_real, R scale) {
+    using C = cpx<R>;
+    using cfg = cols_cfg<R, B, TWO, CW>;
+    constexpr int T = cfg::T, L = cfg::L, NT = cfg::NT, CPT = cfg::CPT, COLS = cfg::COLS, LOGB = ilog2(B);
+    constexpr int CB = (int) sizeof(C), RB = (int) sizeof(R);
+    constexpr int IB = MODE == DSC_MODE_R2C_PACKED ? RB : CB;       // bytes per input element
+    constexpr int OB = MODE == DSC_MODE_C2R_PACKED ? RB : CB;       // bytes per output element
+    constexpr int kOut = 0x7f000000;                                // an offset past every descriptor range: reads 0, stores dropped
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    R *plane = (R *) lds_raw;
+    C *wtab = (C *) (plane + cfg::PLANE);
+
+    const int tid = threadIdx.x;
+    const int c = tid % CW, t = tid / CW;
+    const int slice = blockIdx.x / tiles_per_slice;
+    const int col = (blockIdx.x - slice * tiles_per_slice) * CW + c;
+    const bool live = col < inner;
+
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+        (void *) ((const char *) in + (size_t) slice * in_axis * inner * IB), 0, in_len * inner * IB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
+        (void *) ((char *) out + (size_t) slice * out_axis * inner * OB), 0, out_axis * inner * OB, 0x00020000);
+
+    for (int i = tid; i < cfg::TABLE; i += NT) wtab[i] = tw_full[(long long) i * cfg::TABLE_STRIDE];
+
+    // ---- load: v[j1] = z[T j1 + t]
+    C v[32];
+    // (Measured and dropped: moving the real rows 8 bytes per lane — the two lanes of a column pair splitting the two rows and a
+    // DPP swap putting (re, im) back together — is within +-7 % of this 4-byte form, better at some lengths and worse at others.)
+    if constexpr (MODE == DSC_MODE_R2C_PACKED) {                    // z[m] = (x[2m], x[2m + 1]): two rows of the axis
+        const int voff = live ? (2 * t * inner + col) * RB : kOut;
+        const int row_b = inner * RB, step = 2 * T * inner * RB;
+#pragma unroll
+        for (int j1 = 0; j1 < 32; ++j1) {
+            const cpx<R> a = buf_load_real<kStream>(rin, voff, j1 * step, R{}), b = buf_load_real<kStream>(rin, voff, j1 * step + row_b, R{});
+            v[j1] = C{a.x, b.x};
+        }
+    } else {
+        const int voff = live ? (t * inner + col) * CB : kOut;
+        const int step = T * inner * CB;
+#pragma unroll
+        for (int j1 = 0; j1 < 32; ++j1) v[j1] = buf_load<kStream>(rin, voff, j1 * step, R{});
+    }
+
+    R *stage = plane + c;                                           // stage[k * CW] = component of bin k of this column
+    if constexpr (MODE == DSC_MODE_C2R_PACKED) {
+        // Z[k] = (a + conj b)/2 + wq (a - conj b), a = Y[k], b = Y[L-k], wq = (i/2) conj(W_2L^k), k = T j1 + t (dsc_fft.h:194-228)
+        const C wbase = tw_real[t];
+        C yl = C{(R) 0, (R) 0};
+        if (t == 0) {                                               // bins 0 and L: real parts only (dsc_fft.h:227-228)
+            yl = buf_load<kStream>(rin, live ? col * CB : kOut, L * inner * CB, R{});
+            v[0].y = (R) 0;
+            yl.y = (R) 0;
+        }
+        R dx[32];
+        R *up = stage + t * CW;
+        const R *dn = stage + ((L - 31 * T) - t) * CW;
+#pragma unroll
+        for (int j1 = 0; j1 < 32; ++j1) up[T * j1 * CW] = v[j1].x;
+        if (t == 0) stage[L * CW] = yl.x;
+        lds_barrier();
+#pragma unroll
+        for (int j1 = 0; j1 < 32; ++j1) {
+            const R bx = dn[T * (31 - j1) * CW];
+            dx[j1] = v[j1].x - bx;
+            v[j1].x = v[j1].x + bx;
+        }
+        lds_barrier();
+#pragma unroll
+        for (int j1 = 0; j1 < 32; ++j1) up[T * j1 * CW] = v[j1].y;
+        if (t == 0) stage[L * CW] = yl.y;
+        lds_barrier();
+#pragma unroll
+        for (int j1 = 0; j1 < 32; ++j1) {
+            const R by = dn[T * (31 - j1) * CW];
+            const C w = cmul(wbase, C{(R) root64_re(j1), (R) root64_im(j1)});      // W_2L^{t + T j1} = W_2L^t W_64^{j1}
+            const R wqx = (R) 0.5 * w.y, wqy = (R) 0.5 * w.x;
+            const R sy = v[j1].y - by, dy = v[j1].y + by;
+            const R zx = (R) 0.5 * v[j1].x + (dx[j1] * wqx - dy * wqy);
+            const R zy = (R) 0.5 * sy + (dx[j1] * wqy + dy * wqx);
+            v[j1] = C{zx, zy};
+        }
+    }
+    __syncthreads();                // twiddle table visible; staging reads done before the plane is reused
+
+    cols_passes<R, B, TWO, CW, INV>(v, plane, wtab, tw_full, t, c);
+
+    if constexpr (MODE == DSC_MODE_C2C) {
+        const int voff = live ? (t * inner + col) * CB : kOut;
+        const int step = inner * CB;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i)
+#pragma unroll
+            for (int p = 0; p < B; ++p) {
+                const C r = v[i * B + p];
+                buf_store<kStream>(C{r.x * scale, r.y * scale}, rout, voff, (T * i + COLS * brev(p, LOGB)) * step);
+            }
+    } else if constexpr (MODE == DSC_MODE_C2R_PACKED) {             // sample pair (2k, 2k + 1) = (re, im) of z[k]: two rows of the output axis
+        const int voff = live ? (2 * t * inner + col) * RB : kOut;
+        const int row_b = inner * RB;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i)
+#pragma unroll
+            for (int p = 0; p < B; ++p) {
+                const C r = v[i * B + p];
+                const int soff = 2 * (T * i + COLS * brev(p, LOGB)) * row_b;
+                store_real(r.x * scale, rout, voff, soff);
+                store_real(r.y * scale, rout, voff, soff + row_b);
+            }
+    } else {
+        // packed-real post-pass (dsc_fft.h:199-225), one thread per PAIR (k, L-k), k = t + T i < L/2, plus k = L/2 (thread 0)
+        const C wbase = tw_real[t];
+        R ax[16], bx[16], amx = (R) 0;
+        R *up = stage + t * CW;
+        const R *dn = stage + ((L - 15 * T) - t) * CW;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i)
+#pragma unroll
+            for (int p = 0; p < B; ++p) up[(T * i + COLS * brev(p, LOGB)) * CW] = v[i * B + p].x;
+        if (t == 0) stage[L * CW] = v[0].x;                                   // Z[L] := Z[0]
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { ax[i] = up[T * i * CW]; bx[i] = dn[T * (15 - i) * CW]; }
+        if (t == 0) amx = stage[(L / 2) * CW];
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < CPT; ++i)
+#pragma unroll
+            for (int p = 0; p < B; ++p) up[(T * i + COLS * brev(p, LOGB)) * CW] = v[i * B + p].y;
+        if (t == 0) stage[L * CW] = v[0].y;
+        lds_barrier();
+        const int step = inner * CB;
+        const int voff_k = live ? (t * inner + col) * CB : kOut;
+        const int voff_m = live ? (((L - 15 * T) - t) * inner + col) * CB : kOut;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const R ay = up[T * i * CW], by = dn[T * (15 - i) * CW];
+            const C w = cmul(wbase, C{(R) root64_re(i), (R) root64_im(i)});        // W_2L^{t + T i} = W_2L^t W_64^i
+            const R wqx = (R) 0.5 * w.y, wqy = (R) -0.5 * w.x;
+            const R sx = ax[i] + bx[i], sy = ay - by, dx = ax[i] - bx[i], dy = ay + by;
+            const R wdx = dx * wqx - dy * wqy, wdy = dx * wqy + dy * wqx;
+            C xk = C{(R) 0.5 * sx + wdx, (R) 0.5 * sy + wdy};
+            C xm = C{(R) 0.5 * sx - wdx, wdy - (R) 0.5 * sy};
+            if (i == 0 && t == 0) { xk.y = (R) 0; xm.y = (R) 0; }           // dsc_fft.h:221-225 stores exact zeros
+            buf_store<kStream>(C{xk.x * scale, xk.y * scale}, rout, voff_k, T * i * step);
+            buf_store<kStream>(C{xm.x * scale, xm.y * scale}, rout, voff_m, T * (15 - i) * step);
+        }
+        if (t == 0) {                                                     // k = L/2: a = b, W_2L^{L/2} = -i
+            const R ay = stage[(L / 2) * CW];
+            buf_store<kStream>(C{amx * scale, -ay * scale}, rout, voff_k, (L / 2) * step);
+        }
+    }
+}
+
+#ifndef DSC_COLS_CW_1024
+#define DSC_COLS_CW_1024 16
+#endif
+#ifndef DSC_COLS_CW_2048
+#define DSC_COLS_CW_2048 16
+#endif
+#ifndef DSC_COLS_CW_4096
+#define DSC_COLS_CW_4096 8
+#endif
+template<typename R, int B, bool TWO, int CW, int MODE, bool INV>
+void launch_cols_one(const void *in, void *out, long long slices, int inner, int in_axis, int in_len, int out_axis, const void *tw_full,
+                     const void *tw_real, double scale, hipStream_t stream) {
+    using cfg = cols_cfg<R, B, TWO, CW>;
+    constexpr size_t lds = cols_lds_bytes<R, B, TWO, CW>();
+    static unsigned long long attr_devices = 0;
+    if (dsc_first_use_on_device(attr_devices)) {
+        DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) fft_cols_kernel<R, B, TWO, CW, MODE, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    }
+    const int tiles = (inner + CW - 1) / CW;
+    DSC_LAUNCH((fft_cols_kernel<R, B, TWO, CW, MODE, INV>), dim3((unsigned) (slices * tiles)), dim3(cfg::NT), lds, stream, in, out, inner, tiles,
+               in_axis, in_len, out_axis, (const cpx<R> *) tw_full, (const cpx<R> *) tw_real, (R) scale);
+}
+
+template<typename R, int B, bool TWO, int CW>
+void launch_cols_mode(dsc_fft_mode mode, bool inverse, const void *in, void *out, long long slices, int inner, int in_axis, int in_len, int out_axis,
+                      const void *tw_full, const void *tw_real, double scale, hipStream_t stream) {
+    if (mode == DSC_MODE_R2C_PACKED)      launch_cols_one<R, B, TWO, CW, DSC_MODE_R2C_PACKED, false>(in, out, slices, inner, in_axis, in_len, out_axis, tw_full, tw_real, scale, stream);
+    else if (mode == DSC_MODE_C2R_PACKED) launch_cols_one<R, B, TWO, CW, DSC_MODE_C2R_PACKED, true>(in, out, slices, inner, in_axis, in_len, out_axis, tw_full, tw_real, scale, stream);
+    else if (inverse)                     launch_cols_one<R, B, TWO, CW, DSC_MODE_C2C, true>(in, out, slices, inner, in_axis, in_len, out_axis, tw_full, tw_real, scale, stream);
+    else                                  launch_cols_one<R, B, TWO, CW, DSC_MODE_C2C, false>(in, out, slices, inner, in_axis, in_len, out_axis, tw_full, tw_real, scale, stream);
+}
+
+}  // namespace
+
+// Complex lengths with a column kernel.  128 .. 2048, and 4096 for c32 data.  Modes: C2C, R2C_PACKED, C2R_PACKED (a real
+// tensor through dsc_fft — R2C_CAST — keeps the transpose route).
+bool dsc_fft_regs_cols_supports(int L, dsc_fft_mode mode, bool single_precision) {
+    if (mode == DSC_MODE_R2C_CAST) return false;
+    if (L == 128 || L == 256 || L == 512 || L == 1024 || L == 2048) return true;
+    return L == 4096 && single_precision && mode == DSC_MODE_C2C;      // 8 columns per tile: the real modes lose to the transpose route there
+}
+
+// Tensor [slices][axis][inner] (contiguous), transform along `axis`: in has in_axis elements along it of which in_len are
+// used (the rest of the transform length is zero), out has out_axis.  Element counts are in each side's own element type
+// (reals on the real side of the packed modes).  Every slice must stay below 2 GiB (32-bit buffer offsets): the caller checks.
+void dsc_launch_fft_regs_cols(const void *in, void *out, long long slices, int inner, int L, dsc_fft_mode mode, bool inverse, bool single_precision,
+                              const void *tw_full, const void *tw_real, double scale, int in_axis, int in_len, int out_axis, hipStream_t stream) {
+    if (slices <= 0 || inner <= 0) return;
+#define COLS_ARGS mode, inverse, in, out, slices, inner, in_axis, in_len, out_axis, tw_full, tw_real, scale, stream
+    if (single_precision) {
+        switch (L) {
+            case 128:  launch_cols_mode<float, 4, true, 64>(COLS_ARGS); break;
+            case 256:  launch_cols_mode<float, 8, true, 32>(COLS_ARGS); break;
+            case 512:  launch_cols_mode<float, 16, true, 32>(COLS_ARGS); break;
+            case 1024:                                  // real rows are 4 B per column: 32 columns make them whole 128-B lines
+                if (mode == DSC_MODE_R2C_PACKED) launch_cols_mode<float, 32, true, 32>(COLS_ARGS);
+                else                             launch_cols_mode<float, 32, true, DSC_COLS_CW_1024>(COLS_ARGS);
+                break;
+            case 2048: launch_cols_mode<float, 2, false, DSC_COLS_CW_2048>(COLS_ARGS); break;
+            default:   launch_cols_mode<float, 4, false, DSC_COLS_CW_4096>(COLS_ARGS); break;
+        }
+    } else {
+        switch (L) {
+            case 128:  launch_cols_mode<double, 4, true, 64>(COLS_ARGS); break;
+            case 256:  launch_cols_mode<double, 8, true, 32>(COLS_ARGS); break;
+            case 512:  launch_cols_mode<double, 16, true, 16>(COLS_ARGS); break;
+            case 1024: launch_cols_mode<double, 32, true, 16>(COLS_ARGS); break;
+            default:   launch_cols_mode<double, 2, false, 8>(COLS_ARGS); break;
+        }
+    }
+#undef COLS_ARGS
+}

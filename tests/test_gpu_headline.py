@@ -40,7 +40,9 @@ def test_paths_are_the_hand_written_kernels(dsc):
     assert dsc.last_fft_path() == 'r2c_64k_regs'
     dsc.rfft(dsc.from_numpy(np.ones((2, 1 << 21), np.float32)))             # beyond the two-pass kernels
     assert dsc.last_fft_path() == 'generic_4step'
-    dsc.rfft(dsc.from_numpy(np.ones((256, 8), np.float32)), axis=0)         # short strided lines
+    dsc.rfft(dsc.from_numpy(np.ones((256, 8), np.float32)), axis=0)         # strided lines of 128 .. 2048 complex points: the column kernel
+    assert dsc.last_fft_path() == 'regs_cols'
+    dsc.rfft(dsc.from_numpy(np.ones((64, 8), np.float32)), axis=0)          # shorter strided lines: the LDS line kernel
     assert dsc.last_fft_path() == 'generic_lds'
 
 
@@ -488,8 +490,9 @@ def test_two_pass_complex_transforms(dsc, dt, L):
 
 @pytest.mark.parametrize('shape,axis', [((1024, 37), 0), ((3, 4096, 5), 1), ((2, 2, 2048, 3), 2), ((131072, 3), 0)])
 def test_strided_axes_via_transpose(dsc, shape, axis):
-    """Transforms along a non-last axis of 512 points or more run as transpose -> register kernel -> transpose; every
-    transform kind, padded and cropped, against the oracle."""
+    """Transforms along a non-last axis: complex lengths 128 .. 4096 on the column kernel (lanes = neighbouring lines), longer
+    ones as transpose -> register kernel -> transpose, shorter ones on the strided LDS kernel; every transform kind, padded
+    and cropped, against the oracle.  The inner extents here (37, 5, 3) are narrower than a column tile: masked lanes."""
     from oracle import port
     rng = np.random.default_rng(shape[axis])
     n = shape[axis]
@@ -499,7 +502,9 @@ def test_strided_axes_via_transpose(dsc, shape, axis):
             continue
         got = dsc.rfft(dsc.from_numpy(x), n=nn, axis=axis)
         L = (1 << int(np.ceil(np.log2(nn if nn > 0 else n)))) // 2
-        assert (dsc.last_fft_path() in ('generic_lds', 'generic_4step')) == (L < 512), (shape, nn, dsc.last_fft_path())
+        want_path = 'regs_cols' if 128 <= L <= 2048 else None
+        assert (dsc.last_fft_path() == 'regs_cols') == (want_path == 'regs_cols'), (shape, nn, dsc.last_fft_path())
+        assert (dsc.last_fft_path() in ('generic_lds', 'generic_4step')) == (L < 128), (shape, nn, dsc.last_fft_path())
         assert_close(got.numpy(), port.rfft(x, nn, axis), what=f'rfft {shape} axis {axis} n={nn}')
     X = port.rfft(x, -1, axis)
     assert_close(dsc.irfft(dsc.from_numpy(X), axis=axis).numpy(), port.irfft(X, -1, axis), what=f'irfft {shape} axis {axis}')
@@ -508,6 +513,48 @@ def test_strided_axes_via_transpose(dsc, shape, axis):
     assert_close(dsc.ifft(dsc.from_numpy(z), axis=axis).numpy(), port.ifft(z, -1, axis), what=f'ifft {shape} axis {axis}')
     xd = x.astype(np.float64)
     assert_close(dsc.rfft(dsc.from_numpy(xd), axis=axis).numpy(), port.rfft(xd, -1, axis), what=f'f64 rfft {shape} axis {axis}')
+
+
+@pytest.mark.parametrize('dt', [np.float32, np.float64])
+@pytest.mark.parametrize('L', [128, 256, 512, 1024, 2048, 4096])
+def test_column_kernel_every_length_and_mode(dsc, dt, L):
+    """fft_regs_cols.hip: every complex length it serves (f64: up to 2048), every mode, several column tiles with a ragged last
+    one, a leading axis (slices), zero-padded and cropped axes — against the oracle (which is pinned on the reference)."""
+    from oracle import port
+    cdt = np.complex64 if dt == np.float32 else np.complex128
+    rng = np.random.default_rng(L)
+    inner = 70 if L <= 1024 else 21                       # > one tile of 64 / 32 / 16 / 8 columns, not a multiple
+    on_cols = L <= 2048 or dt == np.float32               # complex data; the real modes stop at 2048
+    on_cols_real = L <= 2048
+    # complex transform of length L along axis 1 of [2, L, inner]
+    z = (rng.standard_normal((2, L, inner)) + 1j * rng.standard_normal((2, L, inner))).astype(cdt)
+    Z = dsc.fft(dsc.from_numpy(z), axis=1)
+    assert (dsc.last_fft_path() == 'regs_cols') == on_cols, dsc.last_fft_path()
+    assert_close(Z.numpy(), port.fft(z, -1, 1), what=f'fft L={L}')
+    assert_close(dsc.ifft(dsc.from_numpy(z), axis=1).numpy(), port.ifft(z, -1, 1), what=f'ifft L={L}')
+    # real transform of 2L points along axis 0 of [2L, inner]: full, zero padded (axis shorter than n), cropped (axis longer)
+    x = rng.standard_normal((2 * L, inner)).astype(dt)
+    X = dsc.rfft(dsc.from_numpy(x), axis=0)
+    assert (dsc.last_fft_path() == 'regs_cols') == on_cols_real
+    assert X.shape == (L + 1, inner)
+    want = port.rfft(x, -1, 0)
+    assert_close(X.numpy(), want, what=f'rfft L={L}')
+    assert np.all(X.numpy()[0].imag == 0) and np.all(X.numpy()[-1].imag == 0)
+    xs = x[:2 * L - 37]                                    # odd valid length: the last sample pair is cut
+    assert_close(dsc.rfft(dsc.from_numpy(xs), n=2 * L, axis=0).numpy(), port.rfft(xs, 2 * L, 0), what=f'rfft padded L={L}')
+    xl = np.concatenate([x, x[:50]])
+    assert_close(dsc.rfft(dsc.from_numpy(xl), n=2 * L, axis=0).numpy(), port.rfft(xl, 2 * L, 0), what=f'rfft cropped L={L}')
+    # inverse: full bins, fewer bins than L + 1 (missing ones are zero), imaginary parts of bins 0 and L ignored
+    back = dsc.irfft(dsc.from_numpy(want), axis=0)
+    assert (dsc.last_fft_path() == 'regs_cols') == on_cols_real
+    assert_close(back.numpy(), port.irfft(want, -1, 0), what=f'irfft L={L}')
+    assert rel_l2(back.numpy(), x) <= (1e-5 if dt == np.float32 else 1e-12)
+    Xq = want.copy()
+    Xq[0] += 3j
+    Xq[-1] -= 2j
+    assert_close(dsc.irfft(dsc.from_numpy(Xq), axis=0).numpy(), port.irfft(want, -1, 0), what=f'irfft ignores imag of bins 0, L (L={L})')
+    fewer = want[:L // 2 + 3]
+    assert_close(dsc.irfft(dsc.from_numpy(fewer), n=L + 1, axis=0).numpy(), port.irfft(fewer, L + 1, 0), what=f'irfft padded bins L={L}')
 
 
 @pytest.mark.parametrize('dt', [np.float32, np.float64])

@@ -336,7 +336,7 @@ def test_indexing_errors_abort_like_the_reference():
                 f't = dsc.from_numpy(np.zeros((3, 4), np.float32))\n{stmt}\ndsc.synchronize()\nprint("SURVIVED")')
         r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True)
         assert r.returncode != 0 and 'SURVIVED' not in r.stdout, (name, r.stdout, r.stderr)
-        assert 'DSC_ASSERT' in r.stderr or 'too many' in r.stderr, (name, r.stderr)
+        assert 'dsc_tensor_' in r.stderr or 'DSC_ASSERT' in r.stderr, (name, r.stderr)      # "<entry point>: <the rule that failed>"
 
 
 def test_golden_transpose_and_fftfreq(dsc, golden):
