@@ -247,7 +247,7 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
     lines_of(j.x, j.slot, &n_lines, &inner, &lin);
     lines_of(j.out, j.slot, &n_lines, &inner, &lout);
 
-    // Strided lines of complex length 128 .. 4096: the column kernel (lanes = neighbouring lines), one pass over HBM.
+    // Strided lines of complex length 32 .. 2048 (4096): the column kernel (lanes = neighbouring lines), one pass over HBM.
     static const bool cols_off = getenv("DSC_NO_COLS") != nullptr;            // A/B aid (tools/bench_axis0.py)
     if (inner > 1 && !cols_off && inner < (1LL << 30) && dsc_fft_regs_cols_supports(j.L, j.mode, sp)) {
         const int x_n = j.x->shape[j.slot], out_n = j.out->shape[j.slot];

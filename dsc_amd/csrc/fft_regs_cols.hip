@@ -13,7 +13,8 @@
 //   two passes    L = 32 B:    j = B j1 + j3,        T = B:                          dft32 (j1) . W_L . xchg . dft_B (j3)
 //
 // with the packed-real pre / post pass (dsc_fft.h:194-228) through an LDS staging plane [k][c].  This replaces
-// transpose -> last-axis kernel -> transpose (three passes over HBM, 16-22 % of the roofline) for complex lengths 128 .. 4096.
+// transpose -> last-axis kernel -> transpose (three passes over HBM, 16-22 % of the roofline) and the strided LDS kernel for
+// complex lengths 32 .. 2048 (c32 data: 4096).
 #include "kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -318,11 +319,11 @@ void launch_cols_mode(dsc_fft_mode mode, bool inverse, const void *in, void *out
 
 }  // namespace
 
-// Complex lengths with a column kernel.  128 .. 2048, and 4096 for c32 data.  Modes: C2C, R2C_PACKED, C2R_PACKED (a real
+// Complex lengths with a column kernel.  32 .. 2048, and 4096 for c32 data.  Modes: C2C, R2C_PACKED, C2R_PACKED (a real
 // tensor through dsc_fft — R2C_CAST — keeps the transpose route).
 bool dsc_fft_regs_cols_supports(int L, dsc_fft_mode mode, bool single_precision) {
     if (mode == DSC_MODE_R2C_CAST) return false;
-    if (L == 128 || L == 256 || L == 512 || L == 1024 || L == 2048) return true;
+    if (L == 32 || L == 64 || L == 128 || L == 256 || L == 512 || L == 1024 || L == 2048) return true;
     return L == 4096 && single_precision && mode == DSC_MODE_C2C;      // 8 columns per tile: the real modes lose to the transpose route there
 }
 
@@ -335,6 +336,8 @@ void dsc_launch_fft_regs_cols(const void *in, void *out, long long slices, int i
 #define COLS_ARGS mode, inverse, in, out, slices, inner, in_axis, in_len, out_axis, tw_full, tw_real, scale, stream
     if (single_precision) {
         switch (L) {
+            case 32:   launch_cols_mode<float, 1, true, 256>(COLS_ARGS); break;
+            case 64:   launch_cols_mode<float, 2, true, 128>(COLS_ARGS); break;
             case 128:  launch_cols_mode<float, 4, true, 64>(COLS_ARGS); break;
             case 256:  launch_cols_mode<float, 8, true, 32>(COLS_ARGS); break;
             case 512:  launch_cols_mode<float, 16, true, 32>(COLS_ARGS); break;
@@ -347,6 +350,8 @@ void dsc_launch_fft_regs_cols(const void *in, void *out, long long slices, int i
         }
     } else {
         switch (L) {
+            case 32:   launch_cols_mode<double, 1, true, 256>(COLS_ARGS); break;
+            case 64:   launch_cols_mode<double, 2, true, 128>(COLS_ARGS); break;
             case 128:  launch_cols_mode<double, 4, true, 64>(COLS_ARGS); break;
             case 256:  launch_cols_mode<double, 8, true, 32>(COLS_ARGS); break;
             case 512:  launch_cols_mode<double, 16, true, 16>(COLS_ARGS); break;

@@ -107,7 +107,7 @@ void   dsc_launch_fft32k_c32(const void *z, void *Z, int batch, int in_pitch, in
 void   dsc_launch_filter64k(const float *s, const void *H, float *y, int batch, int in_pitch, int in_len, const void *aux, int n_cu,
                             hipStream_t stream);
 
-// ---- transforms along a non-last axis, lanes = neighbouring lines (fft_regs_cols.hip): complex length 128 .. 4096 (f64: 2048)
+// ---- transforms along a non-last axis, lanes = neighbouring lines (fft_regs_cols.hip): complex length 32 .. 2048 (c32 data: 4096)
 bool   dsc_fft_regs_cols_supports(int L, dsc_fft_mode mode, bool single_precision);
 void   dsc_launch_fft_regs_cols(const void *in, void *out, long long slices, int inner, int L, dsc_fft_mode mode, bool inverse, bool single_precision,
                                 const void *tw_full, const void *tw_real, double scale, int in_axis, int in_len, int out_axis, hipStream_t stream);

@@ -40,9 +40,9 @@ def test_paths_are_the_hand_written_kernels(dsc):
     assert dsc.last_fft_path() == 'r2c_64k_regs'
     dsc.rfft(dsc.from_numpy(np.ones((2, 1 << 21), np.float32)))             # beyond the two-pass kernels
     assert dsc.last_fft_path() == 'generic_4step'
-    dsc.rfft(dsc.from_numpy(np.ones((256, 8), np.float32)), axis=0)         # strided lines of 128 .. 2048 complex points: the column kernel
+    dsc.rfft(dsc.from_numpy(np.ones((256, 8), np.float32)), axis=0)         # strided lines of 32 .. 2048 complex points: the column kernel
     assert dsc.last_fft_path() == 'regs_cols'
-    dsc.rfft(dsc.from_numpy(np.ones((64, 8), np.float32)), axis=0)          # shorter strided lines: the LDS line kernel
+    dsc.rfft(dsc.from_numpy(np.ones((32, 8), np.float32)), axis=0)          # shorter strided lines: the LDS line kernel
     assert dsc.last_fft_path() == 'generic_lds'
 
 
@@ -502,9 +502,9 @@ def test_strided_axes_via_transpose(dsc, shape, axis):
             continue
         got = dsc.rfft(dsc.from_numpy(x), n=nn, axis=axis)
         L = (1 << int(np.ceil(np.log2(nn if nn > 0 else n)))) // 2
-        want_path = 'regs_cols' if 128 <= L <= 2048 else None
+        want_path = 'regs_cols' if 32 <= L <= 2048 else None
         assert (dsc.last_fft_path() == 'regs_cols') == (want_path == 'regs_cols'), (shape, nn, dsc.last_fft_path())
-        assert (dsc.last_fft_path() in ('generic_lds', 'generic_4step')) == (L < 128), (shape, nn, dsc.last_fft_path())
+        assert (dsc.last_fft_path() in ('generic_lds', 'generic_4step')) == (L < 32), (shape, nn, dsc.last_fft_path())
         assert_close(got.numpy(), port.rfft(x, nn, axis), what=f'rfft {shape} axis {axis} n={nn}')
     X = port.rfft(x, -1, axis)
     assert_close(dsc.irfft(dsc.from_numpy(X), axis=axis).numpy(), port.irfft(X, -1, axis), what=f'irfft {shape} axis {axis}')
@@ -516,14 +516,14 @@ def test_strided_axes_via_transpose(dsc, shape, axis):
 
 
 @pytest.mark.parametrize('dt', [np.float32, np.float64])
-@pytest.mark.parametrize('L', [128, 256, 512, 1024, 2048, 4096])
+@pytest.mark.parametrize('L', [32, 64, 128, 256, 512, 1024, 2048, 4096])
 def test_column_kernel_every_length_and_mode(dsc, dt, L):
     """fft_regs_cols.hip: every complex length it serves (f64: up to 2048), every mode, several column tiles with a ragged last
     one, a leading axis (slices), zero-padded and cropped axes — against the oracle (which is pinned on the reference)."""
     from oracle import port
     cdt = np.complex64 if dt == np.float32 else np.complex128
     rng = np.random.default_rng(L)
-    inner = 70 if L <= 1024 else 21                       # > one tile of 64 / 32 / 16 / 8 columns, not a multiple
+    inner = 300 if L <= 64 else 70 if L <= 1024 else 21   # > one tile of 256 / 128 / 64 / 32 / 16 / 8 columns, not a multiple
     on_cols = L <= 2048 or dt == np.float32               # complex data; the real modes stop at 2048
     on_cols_real = L <= 2048
     # complex transform of length L along axis 1 of [2, L, inner]
