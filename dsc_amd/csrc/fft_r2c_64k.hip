@@ -214,7 +214,13 @@ constexpr int kStream = DSC_STREAM_AUX;
 __device__ __forceinline__ cf load_c(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return to_cf(__builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, kStream)));
 }
-// spectrum rows of the inverse kernel (skewed by 8 B x row; see irfft64k_kernel): policy chosen by measurement
+// How many pairs of the NEXT row irfft64k_kernel requests before its last pass (see there): measured 0 / 4 / 6 / 8 pairs ->
+// 0.914 / 0.868 / 0.879 / 0.920 ms (4: no spills at 126 VGPRs; 6 and 8 spill).
+#ifndef DSC_IRFFT_EARLY_PAIRS
+#define DSC_IRFFT_EARLY_PAIRS 4
+#endif
+// spectrum rows of the inverse kernel (skewed by 8 B x row; see irfft64k_kernel): cache policy chosen by measurement (default
+// policy 0.911 ms; sc0 0.911, nt 0.930, sc0 nt 0.929, sc1 0.937, sc0 sc1 0.936, sc1 nt 0.929)
 #ifndef DSC_IRFFT_LOAD_AUX
 #define DSC_IRFFT_LOAD_AUX 0
 #endif
@@ -249,9 +255,13 @@ __device__ __forceinline__ void exchange(float *plane, int wbase, int row, const
 //         `col`, the exchange routes by column: pass `col` = the column this thread holds)
 //   out: v[p] = element col_out + 1024 br5(p) of the output sequence, where the caller picks
 //        which output column `col_out` this thread receives.
-template<bool INV>
+struct no_hook { __device__ __forceinline__ void operator()() const {} };
+
+// `before_pass3` runs between the second exchange and the last 32-point DFT: from there to the end of the row only v[] (64
+// VGPRs) is live, which leaves room to request part of the NEXT row that early (irfft64k_kernel does).
+template<bool INV, typename Hook = no_hook>
 __device__ __forceinline__ void three_passes(cf (&v)[32], float *plane, const f2 *w1024, const f2 *aux, int wave_sgpr,
-                                             bool mirrored_in, bool mirrored_out) {
+                                             bool mirrored_in, bool mirrored_out, Hook before_pass3 = Hook{}) {
     // ---- pass 1 (over the slow index) and twiddle W_1024^{hi r1}, hi = col >> 5
     dft32<INV>(v);
     cf u[32];
@@ -283,6 +293,7 @@ __device__ __forceinline__ void three_passes(cf (&v)[32], float *plane, const f2
         const int col_out = mirrored_out ? column_of(t >> 6, t & 63) : t;
         exchange(plane, hi * kRowPitch + lo, col_out, u, v);
     }
+    before_pass3();
     // ---- pass 3 (over the fast index)
     dft32<INV>(v);
 }
@@ -579,37 +590,52 @@ __global__ __launch_bounds__(1024) void irfft64k_kernel(const f2 *__restrict__ X
             __builtin_amdgcn_make_buffer_rsrc((void *) (x + (size_t) row * 65536), 0, 65536 * 4 * IO_ON, 0x00020000);
 
         inverse_prepass_direct(v, y_mid, aux, wave_sgpr);
-        three_passes<true>(v, plane, w1024, aux, wave_sgpr, true, false);      // v[p] = z[t + 1024 br5(p)]
+        // The next row's first kEarly pairs (the ones the pre-pass consumes first) are requested BEFORE pass 3 — from the second
+        // exchange on only v[] is live, which leaves room for them — the next eight when the first half of this row has left for
+        // the staging area, the rest after the second half.  (kEarly = 0: everything in the tail, as the forward kernel does.)
+        constexpr int kEarly = DSC_IRFFT_EARLY_PAIRS;
+        cf early[kEarly > 0 ? 2 * kEarly : 1];
+        three_passes<true>(v, plane, w1024, aux, wave_sgpr, true, false, [&]() {      // v[p] = z[t + 1024 br5(p)]
+            if constexpr (kEarly > 0) {
+                const int t3 = thread_id(wave_sgpr);
+                const int c3 = column_of(t3 >> 6, t3 & 63);
+                const int pv3 = (kM - c3 - 15 * 1024) * 8;
+#pragma unroll
+                for (int a = 0; a < kEarly; ++a) {
+                    early[2 * a] = load_c_spec(rnext, c3 * 8, a * 8192);
+                    early[2 * a + 1] = load_c_spec(rnext, pv3, (15 - a) * 8192);
+                }
+            }
+        });
 
         const int t4 = thread_id(wave_sgpr);
         const int c = column_of(t4 >> 6, t4 & 63);
         const int pv = (kM - c - 15 * 1024) * 8;
         staged_time_store(v, plane, rout, wave_sgpr, [&](bool first_half) {
-            // consumption order of the pre-pass: pairs 0..7 (and bin M/2) into the even registers, pairs 8..15 into the odd ones
+            // consumption order of the pre-pass: the pairs in ascending order (and bin M/2 with the first)
             if (first_half) {
                 y_mid = cf{0.f, 0.f};
                 if (c == 0) y_mid = load_c_spec(rnext, (kM / 2) * 8, 0);
 #pragma unroll
-                for (int a = 0; a < 8; ++a) {
-                    v[2 * a] = load_c_spec(rnext, c * 8, a * 8192);
-                    v[16 + 2 * a] = load_c_spec(rnext, pv, (15 - a) * 8192);
+                for (int i = 0; i < 8; ++i) {              // the even registers are free now
+                    v[2 * i] = load_c_spec(rnext, c * 8, (kEarly + i) * 8192);
+                    v[16 + 2 * i] = load_c_spec(rnext, pv, (15 - kEarly - i) * 8192);
                 }
             } else {
 #pragma unroll
-                for (int a = 8; a < 16; ++a) {
-                    v[2 * (a - 8) + 1] = load_c_spec(rnext, c * 8, a * 8192);
-                    v[17 + 2 * (a - 8)] = load_c_spec(rnext, pv, (15 - a) * 8192);
+                for (int i = 0; i < 8 - kEarly; ++i) {     // the odd ones
+                    v[2 * i + 1] = load_c_spec(rnext, c * 8, (kEarly + 8 + i) * 8192);
+                    v[17 + 2 * i] = load_c_spec(rnext, pv, (7 - kEarly - i) * 8192);
                 }
             }
         });
         {   // back to the convention above (a renaming, every index is a constant)
             cf nxt[32];
 #pragma unroll
-            for (int a = 0; a < 8; ++a) {
-                nxt[a] = v[2 * a];
-                nxt[16 + a] = v[16 + 2 * a];
-                nxt[8 + a] = v[2 * a + 1];
-                nxt[24 + a] = v[17 + 2 * a];
+            for (int a = 0; a < 16; ++a) {
+                if (a < kEarly)          { nxt[a] = early[2 * a];             nxt[16 + a] = early[2 * a + 1]; }
+                else if (a < kEarly + 8) { nxt[a] = v[2 * (a - kEarly)];      nxt[16 + a] = v[16 + 2 * (a - kEarly)]; }
+                else                     { nxt[a] = v[2 * (a - kEarly - 8) + 1]; nxt[16 + a] = v[17 + 2 * (a - kEarly - 8)]; }
             }
 #pragma unroll
             for (int a = 0; a < 32; ++a) v[a] = nxt[a];
