@@ -216,6 +216,9 @@ __device__ __forceinline__ cf load_c(__amdgpu_buffer_rsrc_t r, int voff, int sof
 }
 // How many pairs of the NEXT row irfft64k_kernel requests before its last pass (see there): measured 0 / 4 / 6 / 8 pairs ->
 // 0.914 / 0.868 / 0.879 / 0.920 ms (4: no spills at 126 VGPRs; 6 and 8 spill).
+#ifndef DSC_FILTER_EARLY_LOADS
+#define DSC_FILTER_EARLY_LOADS 4      // measured 0 / 4 / 12 / 16: 0.669 / 0.662 / 0.664 / 0.673 ms (the kernel is ALU bound; +1 %)
+#endif
 #ifndef DSC_IRFFT_EARLY_PAIRS
 #define DSC_IRFFT_EARLY_PAIRS 4
 #endif
@@ -747,21 +750,29 @@ __global__ __launch_bounds__(1024) void filter64k_kernel(const float *__restrict
         cf z[32];                                          // inverse input in natural row order (a renaming)
 #pragma unroll
         for (int r = 0; r < 32; ++r) z[r] = v[br5(r)];
-        three_passes<true>(z, plane, w1024, aux, wave_sgpr, true, false);      // z[p] = y[2(t + 1024 br5(p)) .. +1]
+        // the next row's first kEarlyX loads are requested before the inverse transform's last pass (see irfft64k_kernel)
+        constexpr int kEarlyX = DSC_FILTER_EARLY_LOADS;
+        cf early[kEarlyX > 0 ? kEarlyX : 1];
+        three_passes<true>(z, plane, w1024, aux, wave_sgpr, true, false, [&]() {      // z[p] = y[2(t + 1024 br5(p)) .. +1]
+            if constexpr (kEarlyX > 0) {
+                const int off = thread_id(wave_sgpr) * 8;
+#pragma unroll
+                for (int j1 = 0; j1 < kEarlyX; ++j1) early[j1] = load_c(rnext, off, j1 * 8192);
+            }
+        });
         {
             const int load_off = thread_id(wave_sgpr) * 8;
             staged_time_store(z, plane, rout, wave_sgpr, [&](bool first_half) {
                 if (first_half) {
 #pragma unroll
-                    for (int j1 = 0; j1 < 16; ++j1) z[2 * j1] = load_c(rnext, load_off, j1 * 8192);
+                    for (int i = 0; i < 16; ++i) z[2 * i] = load_c(rnext, load_off, (kEarlyX + i) * 8192);
                 } else {
 #pragma unroll
-                    for (int j1 = 16; j1 < 32; ++j1) z[2 * (j1 - 16) + 1] = load_c(rnext, load_off, j1 * 8192);
+                    for (int i = 0; i < 16 - kEarlyX; ++i) z[2 * i + 1] = load_c(rnext, load_off, (kEarlyX + 16 + i) * 8192);
                 }
             });
-            unzip_rows(z);
 #pragma unroll
-            for (int j1 = 0; j1 < 32; ++j1) v[j1] = z[j1];
+            for (int j1 = 0; j1 < 32; ++j1) v[j1] = j1 < kEarlyX ? early[j1] : j1 < kEarlyX + 16 ? z[2 * (j1 - kEarlyX)] : z[2 * (j1 - kEarlyX - 16) + 1];
         }
     }
 }
