@@ -359,6 +359,9 @@ __global__ __launch_bounds__(1024) void rfft64k_kernel(const float *__restrict__
             __builtin_amdgcn_make_buffer_rsrc((void *) (X + (size_t) row * (kM + 1)), 0, (kM + 1) * 8 * IO_ON, 0x00020000);
 
         three_passes<false>(v, plane, w1024, aux, wave_sgpr, false, true);     // v[p] = Z[k' + 1024 br5(p)]
+        // (Requesting part of the next row before pass 3, as irfft64k_kernel does, was tried here too: it needs pass 3's results
+        // pinned — the compiler otherwise sinks the butterflies into the post-pass and the merged region takes all 128
+        // registers — and then fits 4 loads, which measured 0.842-0.849 ms against 0.845-0.849 ms: nothing.)
 
         // ---- packed-real post-pass.  Rows 0..15 of this column pair with rows 31..16 of the
         // partner column (odd registers there); fetch them, finish both bins of each pair:
@@ -368,19 +371,21 @@ __global__ __launch_bounds__(1024) void rfft64k_kernel(const float *__restrict__
         const int kp = column_of(wave, lane);
         const int partner_addr = partner_byte_addr(wave, lane);
         cf xk[16], xm[16];
+        const cf zmid = v[br5(16)];                        // Z[M/2] in column 0
+        if (wave_sgpr == 0) {
+            // Column 0 (lane 0, its own partner) pairs row k3 with row 32 - k3 of ITSELF, not 31 - k3: shift its rows 17 .. 31
+            // down by one (and row 0 into row 31) BEFORE the exchange, so that the general fetch below is right for it too and
+            // the sent rows die with their ds_bpermute — fixing the fetched values up afterwards kept all 32 of them alive
+            // across the exchange, in every wave.
+#pragma unroll
+            for (int r = 16; r < 31; ++r) v[br5(r)] = lane == 0 ? v[br5(r + 1)] : v[br5(r)];
+            v[br5(31)] = lane == 0 ? v[br5(0)] : v[br5(31)];
+        }
 #pragma unroll
         for (int k3 = 0; k3 < 16; ++k3) {
             const int src = 31 - br5(k3);                  // = br5(31 - k3)
             xm[k3].x = bperm(partner_addr, v[src].x);
             xm[k3].y = bperm(partner_addr, v[src].y);
-        }
-        const cf zmid = v[br5(16)];                        // Z[M/2] in column 0
-        if (wave == 0) {                                   // column 0 pairs row k3 with row 32 - k3 of itself
-#pragma unroll
-            for (int k3 = 0; k3 < 16; ++k3) {
-                const cf own = v[br5((32 - k3) & 31)];
-                xm[k3] = lane == 0 ? own : xm[k3];
-            }
         }
         {
             const cf wpost = to_cf(aux[kAuxW65536 + kp]);
@@ -393,8 +398,6 @@ __global__ __launch_bounds__(1024) void rfft64k_kernel(const float *__restrict__
             }
         }
 
-        // (Requesting part of the next row earlier, as irfft64k_kernel does before its pass 3, does not fit here: the post-pass
-        // holds all 128 registers, and 4 loads issued right after it — the earliest point without spills — measured +-0.3 %.)
         // ---- store.  Output rows are 32769 bins long, so a row starts 8 * (row mod 16) bytes
         // past a 128-B line; storing each lane's bins where the FFT left them would cut every
         // 256-B piece across three lines (measured: ~20 % of the HBM rate lost to partial
