@@ -215,9 +215,13 @@ __device__ __forceinline__ cf load_c(__amdgpu_buffer_rsrc_t r, int voff, int sof
     return to_cf(__builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, kStream)));
 }
 // How many pairs of the NEXT row irfft64k_kernel requests before its last pass (see there): measured 0 / 4 / 6 / 8 pairs ->
-// 0.914 / 0.868 / 0.879 / 0.920 ms (4: no spills at 126 VGPRs; 6 and 8 spill).
+// 0.914 / 0.868 / 0.879 / 0.920 ms.  With pass 3 pinned (DSC_IRFFT_PIN_PASS3) 4 / 6 / 8 pairs need 116 / 121 / 128 VGPRs without spills
+// and measure 0.868 / 0.870 / 0.884 ms: what pays is the rebalanced tail (8 + 16 + 9 loads instead of 17 + 16), not more prefetch.
 #ifndef DSC_FILTER_EARLY_LOADS
 #define DSC_FILTER_EARLY_LOADS 4      // measured 0 / 4 / 12 / 16: 0.669 / 0.662 / 0.664 / 0.673 ms (the kernel is ALU bound; +1 %)
+#endif
+#ifndef DSC_IRFFT_PIN_PASS3
+#define DSC_IRFFT_PIN_PASS3 1
 #endif
 #ifndef DSC_IRFFT_EARLY_PAIRS
 #define DSC_IRFFT_EARLY_PAIRS 4
@@ -616,6 +620,15 @@ __global__ __launch_bounds__(1024) void irfft64k_kernel(const f2 *__restrict__ X
             }
         });
 
+#if DSC_IRFFT_PIN_PASS3
+        // pass 3 complete here (the compiler otherwise sinks its butterflies towards the staging writes, where they overlap the
+        // loads' registers)
+#pragma unroll
+        for (int p = 0; p < 32; p += 8)
+            asm volatile("" : "+v"(v[p].x), "+v"(v[p].y), "+v"(v[p + 1].x), "+v"(v[p + 1].y), "+v"(v[p + 2].x), "+v"(v[p + 2].y), "+v"(v[p + 3].x),
+                         "+v"(v[p + 3].y), "+v"(v[p + 4].x), "+v"(v[p + 4].y), "+v"(v[p + 5].x), "+v"(v[p + 5].y), "+v"(v[p + 6].x), "+v"(v[p + 6].y),
+                         "+v"(v[p + 7].x), "+v"(v[p + 7].y));
+#endif
         const int t4 = thread_id(wave_sgpr);
         const int c = column_of(t4 >> 6, t4 & 63);
         const int pv = (kM - c - 15 * 1024) * 8;

@@ -106,6 +106,30 @@ def _axis0_small(dsc, B, ctx, np):
     return (lambda: B.dsc_rfft(ctx, x._c_ptr, X._c_ptr, -1, 0)), cols * (n * 4 + (n // 2 + 1) * 8), (x, X)
 
 
+def _axis0_case(n, cols, kind):
+    def make(dsc, B, ctx, np):
+        rng = np.random.default_rng(6)
+        blk = rng.standard_normal((n, 4096)).astype(np.float32)
+        if kind == 'fft':
+            zc = cols // 2
+            z = dsc.from_numpy(np.tile((blk[:, :2048] + 1j * blk[:, 2048:]).astype(np.complex64), (1, zc // 2048)))
+            Z = dsc.empty((n, zc), dsc.Dtype.C32)
+            return (lambda: B.dsc_fft(ctx, z._c_ptr, Z._c_ptr, -1, 0)), 2 * n * zc * 8, (z, Z)
+        x = dsc.from_numpy(np.tile(blk, (1, cols // 4096)))
+        X = dsc.empty((n // 2 + 1, cols), dsc.Dtype.C32)
+        B.dsc_rfft(ctx, x._c_ptr, X._c_ptr, -1, 0)
+        nbytes = n * cols * 4 + (n // 2 + 1) * cols * 8
+        if kind == 'irfft':
+            return (lambda: B.dsc_irfft(ctx, X._c_ptr, x._c_ptr, -1, 0)), nbytes, (x, X)
+        return (lambda: B.dsc_rfft(ctx, x._c_ptr, X._c_ptr, -1, 0)), nbytes, (x, X)
+    return make
+
+
+for _n, _cols in ((256, 1 << 20), (1024, 1 << 18), (2048, 1 << 17)):
+    for _kind in ('rfft', 'irfft', 'fft'):
+        CASES[f'{_kind}_axis0_{_n}x{_cols if _kind != "fft" else _cols // 2}'] = _axis0_case(_n, _cols, _kind)
+
+
 @case('mul_c32_bcast')
 def _mul(dsc, B, ctx, np):
     S = dsc.empty((4096, 32769), dsc.Dtype.C32)
