@@ -55,6 +55,8 @@ CASES['rfft_c5_f64_262144'] = _rfft_case(262144, 2048, f64=True)
 CASES['irfft_c5_f64_262144'] = _rfft_case(262144, 2048, f64=True, inverse=True)
 CASES['rfft_f32_131072'] = _rfft_case(131072, 4096)
 CASES['rfft_f32_524288'] = _rfft_case(524288, 1024)
+CASES['irfft_f32_131072'] = _rfft_case(131072, 4096, inverse=True)
+CASES['irfft_f32_524288'] = _rfft_case(524288, 1024, inverse=True)
 CASES['rfft_f32_1024'] = _rfft_case(1024, 524288)
 CASES['irfft_f32_1024'] = _rfft_case(1024, 524288, inverse=True)
 CASES['rfft_f32_4096'] = _rfft_case(4096, 131072)
