@@ -165,11 +165,13 @@ int orc_rfft_out_shape(const orc_tensor *x, int n, int axis, int forward, int ou
     int out_n;
     if (forward) {
         const int order = orc_pow2_n(n > 0 ? n : x_n) >> 1;
+        if (order < 1) return -1;               /* a length-1 transform: dsc_plan_fft(0) trips DSC_ASSERT(n > 0) in dsc_pow2_n (dsc.h:124) */
         out_n = order + 1;
         if      (x->dtype == ORC_F32) *out_dtype = ORC_C32;
         else if (x->dtype == ORC_F64) *out_dtype = ORC_C64;
         else return -1;                         /* "RFFT input must be real" */
     } else {
+        if ((n > 0 ? n : x_n) < 2) return -1;   /* dsc_pow2_n(0): DSC_ASSERT(n > 0) (dsc.h:124, dsc.cpp:2199) */
         const int order = orc_pow2_n((n > 0 ? n : x_n) - 1);
         out_n = order << 1;
         if      (x->dtype == ORC_C32) *out_dtype = ORC_F32;

@@ -147,3 +147,21 @@ def test_max_min_with_nans_restatement_equals_reference():
             for axis in (0, 1, 2):
                 a, b = port.reduce(x, op, axis), R.reduce(x, op, axis)
                 assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.nan_to_num(a, nan=0.0), np.nan_to_num(b, nan=0.0)), (dt, op, axis)
+
+
+def test_length_one_real_transforms_abort_in_the_reference_and_are_refused_by_the_restatement():
+    """rfft of one sample (order 0) and irfft of one bin reach dsc_pow2_n(0) / dsc_plan_fft(0), whose DSC_ASSERT(n > 0) ends the
+    process (dsc.h:122-132, dsc.cpp:2195-2200): the restatement's shape rule reports that instead of inventing a result."""
+    import subprocess
+    import sys
+    cases = {'rfft_len1': ('rfft', 'np.ones((3, 1), np.float32)', -1), 'rfft_n1': ('rfft', 'np.ones((3, 8), np.float64)', 1),
+             'irfft_1bin': ('irfft', 'np.ones((2, 1), np.complex64)', -1), 'irfft_n1': ('irfft', 'np.ones((2, 5), np.complex128)', 1)}
+    for name, (op, arr, n) in cases.items():
+        code = f'import numpy as np\nfrom oracle import ref\nr = ref.Ref.get(1 << 26, 1 << 24)\nr.{op}({arr}, {n}, -1)\nprint("SURVIVED")'
+        p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True)
+        assert p.returncode != 0 and 'SURVIVED' not in p.stdout, (name, p.stdout, p.stderr[-300:])
+        with pytest.raises(ValueError):
+            getattr(port, op)(eval(arr), n, -1)
+    # the shortest lengths that do work
+    assert port.rfft(np.ones((3, 2), np.float32)).shape == (3, 2)
+    assert port.irfft(np.ones((3, 2), np.complex64)).shape == (3, 2)
