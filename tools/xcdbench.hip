@@ -17,8 +17,8 @@
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
-constexpr int kRowB = 2 << 20;               // bytes per row (in, scratch and out)
-constexpr int kRowE = kRowB / 16;            // 16-B elements per row
+constexpr int kRowB2M = 2 << 20;             // bytes per row (in, scratch and out): config 5
+constexpr int kTotalE = 2048 * (kRowB2M / 16); // 16-B elements of the whole input
 
 __device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)); }   // HW_REG_XCC_ID[3:0]
 
@@ -37,9 +37,9 @@ __device__ __forceinline__ void l2_counter_add(unsigned *p) {
     asm volatile("global_atomic_add %0, %1, off" : : "v"(p), "v"(1u) : "memory");
 }
 
-__global__ void init_rows(u4 *in, long long rows) {
+__global__ void init_rows(u4 *in, long long total, int row_e) {
     const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < rows * kRowE) in[i] = u4{(unsigned) (i / kRowE), (unsigned) (i % kRowE), 0x5a5a5a5au, 0u};
+    if (i < total) in[i] = u4{(unsigned) (i / row_e), (unsigned) (i % row_e), 0x5a5a5a5au, 0u};
 }
 
 __global__ void xcc_map(unsigned *out) {
@@ -49,10 +49,11 @@ __global__ void xcc_map(unsigned *out) {
 // T threads, E elements of 16 B per thread and task.  SCR: 0 = no scratch (copy, no barriers), 1 = one scratch row + two
 // barriers per row, 2 = two scratch rows + one barrier per row.  PF: request the next row before waiting at the barrier.
 // SPOL: aux bits of the scratch loads (16 = sc1: device scope, misses the L1).
-template<int T, int E, int SCR, bool PF, int SPOL, int TPX = 1>
-__global__ __launch_bounds__(T, (TPX * T / 256)) void team_walk(const u4 *__restrict__ in, u4 *__restrict__ out, u4 *scratch, unsigned *bars, unsigned *team_ids,
+template<int T, int E, int SCR, bool PF, int SPOL, int TPX, int kRowB, int WPC>
+__global__ __launch_bounds__(T, (WPC * T / 256)) void team_walk(const u4 *__restrict__ in, u4 *__restrict__ out, u4 *scratch, unsigned *bars, unsigned *team_ids,
                                                unsigned *errs, int rows, int delay, unsigned long long *stamps) {
     extern __shared__ unsigned lds[];
+    constexpr int kRowE = kRowB / 16;
     const int tid = threadIdx.x;
     // team = XCC the workgroup runs on; rank = order of arrival
     if (tid == 0) {
@@ -140,19 +141,26 @@ __global__ __launch_bounds__(T, (TPX * T / 256)) void team_walk(const u4 *__rest
     if (tid == 0) stamps[2 * (team * 64 + q) + 1] = wall_clock64();
 }
 
-struct bufs { u4 *in, *out, *scratch; unsigned *bars, *team_ids, *errs; int rows; unsigned long long *stamps; };
+struct bufs { u4 *in, *out, *scratch; unsigned *bars, *team_ids, *errs; int rows; unsigned long long *stamps; int row_e; };
 
-template<int T, int E, int SCR, bool PF, int SPOL, int TPX = 1>
-void run(const bufs &b, int wg_per_cu, const char *name, int delay = 0) {
+template<int T, int E, int SCR, bool PF, int SPOL, int TPX, int kRowB, int WPC>
+void run_wpc(bufs &b, const char *name, int delay) {
+    const int wg_per_cu = WPC;
+
+    constexpr int kRowE = kRowB / 16;
     const int TS = kRowE / (T * E), grid = 8 * TS * TPX;
-    const int lds = wg_per_cu == 1 ? 96 * 1024 : 48 * 1024;     // keeps the residency at wg_per_cu
-    auto k = team_walk<T, E, SCR, PF, SPOL, TPX>;
+    if (b.row_e != kRowE) {
+        hipLaunchKernelGGL(init_rows, dim3((unsigned) (kTotalE / 256)), dim3(256), 0, 0, b.in, (long long) kTotalE, kRowE);
+        b.row_e = kRowE; b.rows = kTotalE / kRowE;
+    }
+    const int lds = wg_per_cu == 1 ? 96 * 1024 : wg_per_cu == 2 ? 48 * 1024 : 36 * 1024;     // keeps the residency at wg_per_cu
+    auto k = team_walk<T, E, SCR, PF, SPOL, TPX, kRowB, WPC>;
     CK(hipFuncSetAttribute((const void *) k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipEvent_t a, c; CK(hipEventCreate(&a)); CK(hipEventCreate(&c));
     float best = 1e30f;
     unsigned errs[4] = {0, 0, 0, 0};
     for (int r = 0; r < 4; ++r) {
-        CK(hipMemsetAsync(b.bars, 0, 16 * 64 * 4, 0));
+        CK(hipMemsetAsync(b.bars, 0, 64 * 64 * 4, 0));
         CK(hipMemsetAsync(b.team_ids, 0, 16 * 4, 0));
         CK(hipEventRecord(a));
         hipLaunchKernelGGL(k, dim3(grid), dim3(T), lds, 0, b.in, b.out, b.scratch, b.bars, b.team_ids, b.errs, b.rows, delay, b.stamps);
@@ -162,32 +170,38 @@ void run(const bufs &b, int wg_per_cu, const char *name, int delay = 0) {
     }
     CK(hipMemcpy(errs, b.errs, sizeof errs, hipMemcpyDeviceToHost));
     CK(hipMemset(b.errs, 0, sizeof errs));
-    std::vector<unsigned long long> st(2 * 16 * 64);
+    std::vector<unsigned long long> st(2 * 64 * 64);
     CK(hipMemcpy(st.data(), b.stamps, st.size() * 8, hipMemcpyDeviceToHost));
     unsigned long long t0 = ~0ull;
     for (int t = 0; t < 8 * TPX; ++t) for (int q = 0; q < TS; ++q) if (st[2 * (t * 64 + q)] < t0) t0 = st[2 * (t * 64 + q)];
-    char spans[256]; int n = 0;
+    char spans[1024]; int n = 0;
     for (int t = 0; t < 8 * TPX; t += 8) {          // teams on XCD 0
         unsigned long long lo = ~0ull, hi = 0;
         for (int q = 0; q < TS; ++q) { lo = st[2 * (t * 64 + q)] < lo ? st[2 * (t * 64 + q)] : lo; hi = st[2 * (t * 64 + q) + 1] > hi ? st[2 * (t * 64 + q) + 1] : hi; }
         n += snprintf(spans + n, sizeof spans - n, " team %d: %.0f..%.0f us", t, (lo - t0) / 100.0, (hi - t0) / 100.0);
     }
     printf("%-58s delay %d grid %4d x %4d  %8.3f ms  %6.0f GB/s (in+out)  stale %u  uneven %u  timeouts %u\n", name, delay, grid, T, best,
-           2.0 * b.rows * kRowB / best / 1e6, errs[0], errs[1], errs[2]);
+           2.0 * kTotalE * 16 / best / 1e6, errs[0], errs[1], errs[2]);
     printf("      %s\n", spans);
     fflush(stdout);
+}
+
+template<int T, int E, int SCR, bool PF, int SPOL, int TPX = 1, int kRowB = kRowB2M>
+void run(bufs &b, int wg_per_cu, const char *name, int delay = 0) {
+    if (wg_per_cu == 1) run_wpc<T, E, SCR, PF, SPOL, TPX, kRowB, 1>(b, name, delay);
+    else if (wg_per_cu == 2) run_wpc<T, E, SCR, PF, SPOL, TPX, kRowB, 2>(b, name, delay);
+    else run_wpc<T, E, SCR, PF, SPOL, TPX, kRowB, 3>(b, name, delay);
 }
 
 int main() {
     bufs b;
     b.rows = 2048;
-    CK(hipMalloc(&b.in, (size_t) b.rows * kRowB)); CK(hipMalloc(&b.out, (size_t) b.rows * kRowB));
-    CK(hipMalloc(&b.scratch, (size_t) 16 * 2 * kRowB));
-    CK(hipMalloc(&b.bars, 16 * 64 * 4)); CK(hipMalloc(&b.team_ids, 16 * 4)); CK(hipMalloc(&b.errs, 16));
+    CK(hipMalloc(&b.in, (size_t) kTotalE * 16)); CK(hipMalloc(&b.out, (size_t) kTotalE * 16));
+    CK(hipMalloc(&b.scratch, (size_t) 64 * 2 * kRowB2M));
+    CK(hipMalloc(&b.bars, 64 * 64 * 4)); CK(hipMalloc(&b.team_ids, 16 * 4)); CK(hipMalloc(&b.errs, 16));
     CK(hipMemset(b.errs, 0, 16));
-    CK(hipMalloc(&b.stamps, 2 * 16 * 64 * 8)); CK(hipMemset(b.stamps, 0, 2 * 16 * 64 * 8));
-    hipLaunchKernelGGL(init_rows, dim3((unsigned) ((size_t) b.rows * kRowE / 256)), dim3(256), 0, 0, b.in, (long long) b.rows);
-    CK(hipDeviceSynchronize());
+    CK(hipMalloc(&b.stamps, 2 * 64 * 64 * 8)); CK(hipMemset(b.stamps, 0, 2 * 64 * 64 * 8));
+    b.row_e = 0;
 
     unsigned *map; CK(hipMalloc(&map, 512 * 4));
     hipLaunchKernelGGL(xcc_map, dim3(512), dim3(64), 0, 0, map);
@@ -198,6 +212,7 @@ int main() {
     printf("\nworkgroups with XCC_ID == blockIdx %% 8: %d of 512\n", rr);
     fflush(stdout);
 
+    if (!getenv("XCD_ONLY_SMALL")) {
     run<256, 16, 0, true, 0>(b, 1, "copy, no scratch, 256 thr x 16, prefetch");
     run<512, 8, 0, true, 0>(b, 1, "copy, no scratch, 512 thr x 8, prefetch");
     run<1024, 4, 0, true, 0>(b, 1, "copy, no scratch, 1024 thr x 4, prefetch");
@@ -222,5 +237,18 @@ int main() {
     }
     run<512, 8, 1, true, 1>(b, 1, "1 scratch row, 2 barriers, 512 x 8, prefetch, sc0 only");
     run<512, 8, 1, true, 0>(b, 1, "1 scratch row, 2 barriers, 512 x 8, prefetch, plain loads");
+    }
+    // rows of 512 KiB (rfft f32 N = 131072) and 1 MiB: several teams per XCD fit the L2
+    constexpr int K512 = 512 << 10, M1 = 1 << 20;
+    run<256, 8, 0, true, 0, 4, K512>(b, 2, "512 KiB rows: copy, 64 wg per XCD");
+    for (int delay : {0, 2, 4}) {
+        run<256, 8, 1, true, 16, 4, K512>(b, 2, "512 KiB rows: 4 teams of 16 per XCD, 256 x 8", delay);
+        run<256, 8, 1, true, 16, 2, K512>(b, 1, "512 KiB rows: 2 teams of 16 per XCD, 256 x 8", delay);
+        run<256, 8, 1, true, 16, 6, K512>(b, 3, "512 KiB rows: 6 teams of 16 per XCD, 256 x 8", delay);
+        run<256, 16, 1, true, 16, 4, K512>(b, 1, "512 KiB rows: 4 teams of 8 per XCD, 256 x 16", delay);
+        run<512, 8, 1, true, 16, 4, K512>(b, 1, "512 KiB rows: 4 teams of 8 per XCD, 512 x 8", delay);
+        run<256, 8, 1, true, 16, 2, M1>(b, 2, "1 MiB rows: 2 teams of 32 per XCD, 256 x 8", delay);
+        run<256, 16, 1, true, 16, 2, M1>(b, 1, "1 MiB rows: 2 teams of 16 per XCD, 256 x 16", delay);
+    }
     return 0;
 }
