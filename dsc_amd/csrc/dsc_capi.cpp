@@ -67,6 +67,15 @@ static void retire_header(dsc_ctx *ctx, dsc_tensor *t) {
     }
 }
 
+void dsc_stream_sync(dsc_ctx *ctx) {
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->async_error != nullptr && *ctx->async_error != 0) {
+        const unsigned e = *ctx->async_error;
+        *ctx->async_error = 0;
+        DSC_LOG_FATAL("a team barrier of the fused L2 transform did not complete (code %u): the launch was not fully resident", e);
+    }
+}
+
 static void release_headers(dsc_ctx *ctx) {
     for (dsc_tensor *t : ctx->live_tensors) {
         dsc_buffer_rec *rec = (dsc_buffer_rec *) t->buffer;
@@ -79,7 +88,7 @@ static void release_headers(dsc_ctx *ctx) {
 extern "C" void dsc_ctx_free(dsc_ctx *ctx) {
     if (ctx == nullptr) return;
     HIP_CHECK(hipSetDevice(ctx->device));
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    dsc_stream_sync(ctx);
     dsc_trace_release(ctx);
     for (hipEvent_t e : ctx->tracer.free_events) HIP_CHECK(hipEventDestroy(e));
     if (ctx->tracer.based) HIP_CHECK(hipEventDestroy(ctx->tracer.base_ev));
@@ -87,6 +96,7 @@ extern "C" void dsc_ctx_free(dsc_ctx *ctx) {
                  (long) (ctx->main.capacity() >> 20), (long) (ctx->scratch.capacity() >> 20));
     release_headers(ctx);
     dsc_peer_release(ctx);
+    if (ctx->async_error != nullptr) HIP_CHECK(hipHostFree(ctx->async_error));
     for (dsc_tensor *t : ctx->tensor_pool) delete t;
     for (dsc_tensor *t : ctx->quarantine) delete t;
     for (auto &plan : ctx->fft_plans) { delete plan; plan = nullptr; }
@@ -114,7 +124,7 @@ extern "C" void dsc_print_mem_usage(dsc_ctx *ctx) {
                  (double) used / (double) total * 1e2);
 }
 
-extern "C" void dsc_synchronize(dsc_ctx *ctx) { HIP_CHECK(hipStreamSynchronize(ctx->stream)); }
+extern "C" void dsc_synchronize(dsc_ctx *ctx) { dsc_stream_sync(ctx); }
 
 extern "C" void *dsc_stream(dsc_ctx *ctx) { return (void *) ctx->stream; }
 
@@ -243,14 +253,14 @@ extern "C" void dsc_copy_from_host(dsc_ctx *ctx, dsc_tensor *dst, const void *sr
     DSC_ASSERT(dst != nullptr && src != nullptr);
     DSC_ASSERT(nbytes <= (size_t) dst->ne * dsc_dtype_size(dst->dtype));
     HIP_CHECK(hipMemcpyAsync(dst->data, src, nbytes, hipMemcpyHostToDevice, ctx->stream));
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));       // src may be pageable and reused by the caller
+    dsc_stream_sync(ctx);       // src may be pageable and reused by the caller
 }
 
 extern "C" void dsc_copy_to_host(dsc_ctx *ctx, const dsc_tensor *src, void *dst, size_t nbytes) {
     DSC_ASSERT(dst != nullptr && src != nullptr);
     DSC_ASSERT(nbytes <= (size_t) src->ne * dsc_dtype_size(src->dtype));
     HIP_CHECK(hipMemcpyAsync(dst, src->data, nbytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    dsc_stream_sync(ctx);
 }
 
 // dsc.cpp:449-479: scalars as one-element 1-D tensors

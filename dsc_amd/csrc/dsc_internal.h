@@ -163,7 +163,11 @@ struct dsc_ctx {
     dsc_tracer tracer;
     std::vector<hipStream_t> peer_streams;             // copy lanes of dsc_peer_push (peer.cpp), created on first use
     hipEvent_t peer_ready = nullptr;
+    unsigned *async_error = nullptr;                   // pinned: error word of the last team-barrier kernel (fft_xcd_fused.hip), checked at every synchronise
 };
+
+// hipStreamSynchronize + the deferred device-side error checks
+void dsc_stream_sync(dsc_ctx *ctx);
 
 // internal helpers shared by the C-ABI translation units
 dsc_tensor *dsc_new_tensor_in(dsc_ctx *ctx, int n_dim, const int *shape, dsc_dtype dtype,

@@ -315,6 +315,26 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
         }
     }
 
+    // 65536-point complex rows (real length 131072), f32: one launch, the four-step intermediate stays in the XCD-local L2
+    // (fft_xcd_fused.hip)
+    static const bool fused_off = getenv("DSC_NO_FUSED_L2") != nullptr;           // A/B aid
+    if ((packed || j.mode == DSC_MODE_C2C) && inner == 1 && !fused_off && dsc_fft_fused_l2_supports(j.L, sp) &&
+        ctx->scratch.capacity() >= dsc_fft_fused_l2_scratch_bytes(j.L, sp) + DSC_DEVICE_ALIGN) {
+        const bool cplx = !packed;
+        const bool fwd = cplx ? !j.inverse : j.mode == DSC_MODE_R2C_PACKED;
+        ctx->scratch.reset();
+        char *blk = ctx->scratch.alloc(dsc_fft_fused_l2_scratch_bytes(j.L, sp));
+        if (ctx->async_error == nullptr) {
+            DSC_KERNEL_CHECK(hipHostMalloc((void **) &ctx->async_error, sizeof(unsigned), hipHostMallocDefault));
+            *ctx->async_error = 0;
+        }
+        if (dsc_launch_fft_fused_l2(j.x->data, j.out->data, n_lines, j.L, packed, !fwd, sp, blk, ctx->async_error, plan->tw_full, plan->tw_real,
+                                    j.x->shape[j.slot], j.in_len, ctx->stream)) {
+            ctx->last_fft_path = cplx ? "c2c_fused_l2" : fwd ? "r2c_fused_l2" : "c2r_fused_l2";
+            return;
+        }
+    }
+
     // long transforms of contiguous rows (config 5 = f64 N = 262144): two passes over HBM, rows kernel + column kernel with
     // the real pass fused (fft_r2c_2pass.hip)
     static const bool two_pass_off = getenv("DSC_NO_TWO_PASS") != nullptr;        // A/B aid (tools/bench_mid.py)

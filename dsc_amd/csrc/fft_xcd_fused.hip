@@ -1,0 +1,489 @@
+// fft_xcd_fused.hip — 65536-point complex rows (real length 131072) in ONE launch, the four-step intermediate held in the L2
+// of the XCD that works on the row instead of making a round trip through HBM (fft_r2c_2pass.hip moves every row twice).
+//
+//   j = j1 + 256 j2   (input),      k = 256 k1 + k2   (output),      j1, k1, j2, k2 < 256
+//   rows  A[j1][k2] = W_L^{j1 k2} * sum_{j2} z[j1 + 256 j2] W_256^{j2 k2}       256-point FFTs, tasks of 16 adjacent j1
+//   cols  Z[256 k1 + k2] = sum_{j1} A[j1][k2] W_256^{j1 k1}                     256-point FFTs, tasks of 16 columns k2
+//   X from Z by the packed-real pass (dsc_fft.h:199-225), fused into the column task
+//
+// A task is 4096 complex = 256 threads x 16 values (256 = 16 x 16: two in-register 16-point passes and one LDS exchange).
+// A row is 16 row tasks, then 16 column tasks, by a TEAM of 16 persistent workgroups that run on the same XCD
+// (HW_REG_XCC_ID), so that the 512 KiB (f32) of A they write and read back stay in that XCD's 4 MiB L2:
+//   * teams form at kernel start from the order in which workgroups of one XCD arrive (a counter per XCD), after one
+//     grid-wide arrival count; the launch is sized to be fully resident;
+//   * the team barrier is a counter in the XCD's own L2 — plain atomics, no agent-scope fence, hence no L2 write-back /
+//     invalidate; A is written with ordinary stores (the L1 is write-through) and read with sc1 loads (miss the L1);
+//   * rows are claimed from a global counter by the team's first workgroup and published at a barrier; the next row's samples
+//     are requested while the team waits at the first barrier of the current one;
+//   * every spin is bounded: a barrier that does not complete writes a code to a pinned host word (the host aborts at the next synchronise).
+// Measured skeleton and the L2 behaviour behind this design: tools/xcdbench.hip, profiles/r02_c5_infinity_cache.md section 3.
+// Reference: dsc_rfft / dsc_irfft / dsc_fft / dsc_ifft (dsc/src/dsc.cpp:1958-2260, dsc_fft.h:57-238).
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <utility>
+
+#include "fft_regs_common.h"
+
+namespace {
+
+constexpr int kNT = 256;                  // threads per workgroup
+constexpr int kTS = 16;                   // workgroups per team = tasks per phase of a row
+constexpr int kMaxTeams = 8;              // teams per XCD
+constexpr int kL = 65536;
+constexpr int kPQ = 276, kPK = 17;        // row-task exchange: line pitch (values), k2' pitch
+#ifndef DSC_FUSED_BINS_STORE
+#define DSC_FUSED_BINS_STORE kCached
+#endif
+constexpr int kCoherent = 16;             // aux bits: sc1 (device scope: the load misses the L1)
+constexpr unsigned kSpinLimit = 1u << 22; // polls (each > 0.5 us) before a barrier gives up
+
+struct fused_ctl {                        // zero before every launch; one 256-B block per writer group (no L2 line shared between XCDs)
+    unsigned arrived, pad0[63];
+    unsigned row_counter, pad1[63];
+    unsigned xcc_count[8][64];
+    unsigned team[8 * kMaxTeams][64];     // [0] barrier counter, [4] / [5] rows published by the team's first workgroup
+};
+
+__device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)); }   // HW_REG_XCC_ID[3:0]
+
+// atomics that execute in the issuing XCD's L2 (no scope bits)
+__device__ __forceinline__ unsigned l2_fetch_add(unsigned *p, unsigned v) {
+    unsigned r;
+    asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p), "v"(v) : "memory");
+    return r;
+}
+__device__ __forceinline__ void l2_add(unsigned *p, unsigned v) { asm volatile("global_atomic_add %0, %1, off" : : "v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void l2_store(unsigned *p, unsigned v) {
+    asm volatile("global_store_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : : "v"(p), "v"(v) : "memory");
+}
+
+template<typename R, bool INV, int M, int G, int... K>
+__device__ __forceinline__ void x_group(cpx<R> (&v)[16], std::integer_sequence<int, K...>) {
+    (([&] {
+         const cpx<R> u = v[G + K] + v[G + K + M / 2];
+         const cpx<R> d = v[G + K] - v[G + K + M / 2];
+         v[G + K] = u;
+         v[G + K + M / 2] = mul_root<R, INV, M, K>(d);
+     }()),
+     ...);
+}
+template<typename R, bool INV, int M, int... G>
+__device__ __forceinline__ void x_stage(cpx<R> (&v)[16], std::integer_sequence<int, G...>) {
+    (x_group<R, INV, M, G * M>(v, std::make_integer_sequence<int, M / 2>{}), ...);
+}
+// 16-point DFT, natural order in, v[p] = bin brev(p, 4)
+template<typename R, bool INV>
+__device__ __forceinline__ void dft16(cpx<R> (&v)[16]) {
+    x_stage<R, INV, 16>(v, std::make_integer_sequence<int, 1>{});
+    x_stage<R, INV, 8>(v, std::make_integer_sequence<int, 2>{});
+    x_stage<R, INV, 4>(v, std::make_integer_sequence<int, 4>{});
+    x_stage<R, INV, 2>(v, std::make_integer_sequence<int, 8>{});
+}
+
+// W_L^{j1 (tau + 16 k)}, k = 4 a + b: W_L^{j1 tau} W_L^{64 j1 a} W_L^{16 j1 b}, three exact table values
+template<typename R, bool CONJ, bool BREV>
+__device__ __forceinline__ void four_step_twiddle16(cpx<R> (&v)[16], const cpx<R> *twL, int j1, int tau) {
+    using C = cpx<R>;
+    const C base = twL[j1 * tau];
+    const C b1 = twL[16 * j1], b2 = twL[32 * j1], b3 = twL[48 * j1];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const C bq = a == 0 ? base : cmul(base, twL[64 * j1 * a]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const C w = b == 0 ? bq : b == 1 ? cmul(bq, b1) : b == 2 ? cmul(bq, b2) : cmul(bq, b3);
+            const int k = 4 * a + b;
+            const int r = BREV ? brev(k, 4) : k;
+            v[r] = CONJ ? cmulc(v[r], w) : cmul(v[r], w);
+        }
+    }
+}
+
+// REAL: dsc_rfft (forward) / dsc_irfft (INV).  !REAL: dsc_fft / dsc_ifft of complex rows.
+// ext  = the time-domain side (forward input, inverse output): row pitch ext_pitch_b bytes, ext_len_b valid bytes
+// bins = the frequency-domain side: row pitch bins_pitch bins, bins_len valid bins
+template<typename R, bool REAL, bool INV>
+__global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : 1)) void fused_l2_kernel(const char *__restrict__ ext, char *__restrict__ ext_out,
+                                                                               const cpx<R> *__restrict__ bins_in, cpx<R> *__restrict__ bins_out,
+                                                                               cpx<R> *scratch, fused_ctl *ctl, unsigned *host_error, int rows,
+                                                                               const cpx<R> *__restrict__ twL, const cpx<R> *__restrict__ tw_real, R scale,
+                                                                               long long ext_pitch_b, int ext_len_b, long long bins_pitch, int bins_len) {
+    using C = cpx<R>;
+    constexpr int CB = (int) sizeof(C), L = kL, NC = 16, H = 8;
+    constexpr int BL = REAL ? kCached : kStream;                    // spectrum rows of the real transforms are skewed: fft_r2c_2pass.hip
+    // ... and written in 64-B pieces that straddle sectors: with the default policy the pieces of the 16 column tasks of a row
+    // (same XCD, same moment) meet in the L2 and leave as whole lines
+    constexpr int BS = REAL ? DSC_FUSED_BINS_STORE : kStream;
+    __shared__ __attribute__((aligned(16))) R plane[16 * kPQ];      // row task: 16 lines x kPQ; column task: [k1][ell] 257 x 16
+    __shared__ C w256[256];
+    __shared__ int info[8];
+    const int tid = threadIdx.x;
+    w256[tid] = twL[tid * (L / 256)];
+
+    // ---- teams
+    if (tid == 0) {
+        const unsigned x = xcc_id();
+        const unsigned arr = l2_fetch_add(&ctl->xcc_count[x][0], 1u);
+        info[0] = (int) x; info[1] = (int) arr; info[2] = 0;
+        atomicAdd(&ctl->arrived, 1u);
+        unsigned spins = 0;
+        while (atomicAdd(&ctl->arrived, 0u) < gridDim.x) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > kSpinLimit) { __hip_atomic_store(host_error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); info[2] = 1; break; }
+        }
+        info[3] = (int) (l2_fetch_add(&ctl->xcc_count[x][0], 0u) / kTS);
+    }
+    __syncthreads();
+    if (info[2]) return;
+    // wave-uniform values read from LDS: readfirstlane keeps the descriptors built from them in SGPRs (no waterfall loops)
+    const int arrival = __builtin_amdgcn_readfirstlane(info[1]);
+    const int xcc = __builtin_amdgcn_readfirstlane(info[0]), team = arrival / kTS, rank = arrival % kTS;
+    if (team >= __builtin_amdgcn_readfirstlane(info[3]) || team >= kMaxTeams) return;               // workgroups that do not fill a team
+    unsigned *tb = &ctl->team[xcc * kMaxTeams + team][0];
+    C *scr = scratch + (size_t) (xcc * kMaxTeams + team) * L;
+    const __amdgpu_buffer_rsrc_t rwork = __builtin_amdgcn_make_buffer_rsrc((void *) scr, 0, L * CB, 0x00020000);
+    unsigned target = 0;
+    bool broken = false;
+
+    // arrive: everything this workgroup stored is in the L2; wait: the whole team has arrived.  `publish`: the team's first
+    // workgroup claims the row after next and leaves it in slot `slot` before it arrives; everyone reads it when the barrier opens.
+    auto arrive = [&](bool stores_pending, int slot) {
+        target += kTS;
+        if (stores_pending) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        if (tid == kNT - 1) {
+            if (rank == 0 && slot >= 0) l2_store(tb + 4 + slot, atomicAdd(&ctl->row_counter, 1u));
+            l2_add(tb, 1u);
+        }
+    };
+    auto spin = [&](int slot) {
+        if (tid == kNT - 1) {
+            unsigned spins = 0;
+            while ((int) (l2_fetch_add(tb, 0u) - target) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > kSpinLimit) { __hip_atomic_store(host_error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); info[2] = 1; break; }
+            }
+            if (slot >= 0) info[4 + slot] = (int) l2_fetch_add(tb + 4 + slot, 0u);
+        }
+    };
+    auto join = [&]() {
+        lds_barrier();
+        broken = info[2] != 0;
+    };
+
+    // ---- lane roles
+    // row task `rank`: lines j1 = 16 rank + q
+    //   writer lanes tid = 16 s + q: hold z[j1 + 256 (s + 16 m)], m < 16   (pieces of 16 adjacent j1)
+    //   reader lanes tid = 16 q + tau: hold A[j1][tau + 16 k], k < 16       (pieces of 16 adjacent k2)
+    const int wq = tid & 15, ws = tid >> 4;
+    const int rq = tid >> 4, rtau = tid & 15;
+    const int zoff = ((16 * rank + wq) + 256 * ws) * CB;       // REAL: z[j] = (x[2j], x[2j + 1])
+    const int aoff = ((16 * rank + rq) * 256 + rtau) * CB;
+    const int j1r = 16 * rank + rq;
+    constexpr int ZSTEP = 16 * 256 * CB, ASTEP = 16 * CB;
+    // column task `rank`: lanes tid = 16 t + ell: column ell (REAL: 8 columns 8 b + 1 .. 8 b + 8 and their mirrors; column 0
+    // takes the place of the duplicate 128 in the last block), slice t of the 256-point axis (j1 = t + 16 i; k1 = t + 16 k)
+    const int ell = tid & 15, t = tid >> 4;
+    const bool last = rank == kTS - 1;
+    const bool col0 = REAL && last && ell == H;
+    const int col = !REAL ? NC * rank + ell : col0 ? 0 : ell < H ? H * rank + 1 + ell : 256 - H - H * rank + (ell - H);
+    const int ellp = (last && (ell == H - 1 || ell == H)) ? ell : NC - 1 - ell;
+    const int woff = (t * 256 + col) * CB, boff = (256 * t + col) * CB;     // bin 256 (t + 16 k) + col: + k * 16 BSTEP
+    constexpr int WSTEP = 16 * 256 * CB, BSTEP = 256 * CB;
+    R *mine = plane + t * NC + ell;                                  // plane[k1 = t + 16 k][ell]: + k * 16 NC
+    const R *theirs = plane + (15 - t) * NC + ellp + (col0 ? NC : 0);     // plane[255 - k1 (+ 1 in column 0)][ellp]: + (15 - k) * 16 NC
+    const C wt0 = REAL ? cmul(tw_real[col], tw_real[256 * t]) : C{(R) 1, (R) 0};      // W_2L^{256 t + col}
+
+    int next = 0;
+    C cur[16], nxt[16];
+    C cur_last = C{(R) 0, (R) 0}, nxt_last = C{(R) 0, (R) 0};
+    auto request = [&](C (&dst)[16], C &dlast, int row) {
+        if constexpr (!INV) {
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *) (ext + (size_t) row * ext_pitch_b), 0, ext_len_b, 0x00020000);
+#pragma unroll
+            for (int m = 0; m < 16; ++m) dst[m] = buf_load<kStream>(r, zoff, m * ZSTEP, R{});
+        } else {
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *) (bins_in + (size_t) row * bins_pitch), 0, bins_len * CB, 0x00020000);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dst[e] = buf_load<BL>(r, boff, 16 * e * BSTEP, R{});
+            if (REAL && col0 && t == 0) dlast = buf_load<BL>(r, L * CB, 0, R{});
+        }
+    };
+
+    // Second barrier of a row, split: ARRIVE as soon as this workgroup's reads of A have landed (they return in order, ahead of
+    // the 16 or 17 loads of the next row requested right behind them), WAIT only before the next row's A is stored — the
+    // barrier's latency hides behind the column task and the next row task.
+    auto release_scratch = [&]() {
+        // (the fences keep the compiler from moving the request ahead of the reads of A: the count below relies on the order)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (next < rows) { request(nxt, nxt_last, next); __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+        else             { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        arrive(false, -1);
+    };
+
+    // ---- the first two rows of this team
+    if (rank == 0 && tid == kNT - 1) {
+        l2_store(tb + 4, atomicAdd(&ctl->row_counter, 1u));
+        l2_store(tb + 5, atomicAdd(&ctl->row_counter, 1u));
+    }
+    arrive(false, -1);
+    spin(-1);
+    join();
+    if (broken) return;
+    if (tid == kNT - 1) { info[4] = (int) l2_fetch_add(tb + 4, 0u); info[5] = (int) l2_fetch_add(tb + 5, 0u); }
+    lds_barrier();
+    int row = __builtin_amdgcn_readfirstlane(info[4]);
+    next = __builtin_amdgcn_readfirstlane(info[5]);
+    if (row < rows) request(cur, cur_last, row);
+
+    for (int it = 0; row < rows; ++it) {
+        const int slot = it & 1;                                    // slot of `row`: free once everyone holds `row` and `next`
+        C u[16], v[16];
+        if constexpr (!INV) {
+            // ================= row task: samples -> A (scratch)
+            dft16<R, false>(cur);                                   // over m -> k2' in cur[brev(k2')]
+#pragma unroll
+            for (int k = 1; k < 16; ++k) cur[brev(k, 4)] = cmul(cur[brev(k, 4)], w256[ws * k]);
+            R *wr = plane + wq * kPQ + ws;
+            const R *rd = plane + rq * kPQ + rtau * kPK;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) wr[k * kPK] = cur[brev(k, 4)].x;
+            lds_barrier();
+#pragma unroll
+            for (int m = 0; m < 16; ++m) v[m].x = rd[m];
+            lds_barrier();
+#pragma unroll
+            for (int k = 0; k < 16; ++k) wr[k * kPK] = cur[brev(k, 4)].y;
+            lds_barrier();
+#pragma unroll
+            for (int m = 0; m < 16; ++m) v[m].y = rd[m];
+            dft16<R, false>(v);                                     // over s -> k in v[brev(k)]: k2 = tau + 16 k
+            four_step_twiddle16<R, false, true>(v, twL, j1r, rtau);
+            if (it > 0) {                                           // the team has finished READING the previous row's A
+                spin(-1);
+                join();
+                if (broken) return;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) buf_store<kCached>(v[brev(k, 4)], rwork, aoff, k * ASTEP);
+            arrive(true, slot);
+            spin(slot);
+            join();
+            if (broken) return;
+            // ================= column task: A -> bins
+            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *) (bins_out + (size_t) row * bins_pitch), 0, bins_len * CB, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = buf_load<kCoherent>(rwork, woff, i * WSTEP, R{});
+            release_scratch();
+            dft16<R, false>(v);                                     // over i -> k1' in v[brev(k1')]
+#pragma unroll
+            for (int k = 1; k < 16; ++k) v[brev(k, 4)] = cmul(v[brev(k, 4)], w256[t * k]);
+            {
+                R *xw = plane + t * NC + ell;                       // plane[k1'][t][ell]
+                const R *xr = plane + t * 16 * NC + ell;            // thread (ell, t = k1') reads every slice t'
+#pragma unroll
+                for (int k = 0; k < 16; ++k) xw[k * 16 * NC] = v[brev(k, 4)].x;
+                lds_barrier();
+#pragma unroll
+                for (int tp = 0; tp < 16; ++tp) u[tp].x = xr[tp * NC];
+                lds_barrier();
+#pragma unroll
+                for (int k = 0; k < 16; ++k) xw[k * 16 * NC] = v[brev(k, 4)].y;
+                lds_barrier();
+#pragma unroll
+                for (int tp = 0; tp < 16; ++tp) u[tp].y = xr[tp * NC];
+                lds_barrier();
+            }
+            dft16<R, false>(u);                                     // over t' -> k: u[p] = Z[k1 = t + 16 brev(p)][col]
+            if constexpr (!REAL) {
+#pragma unroll
+                for (int p = 0; p < 16; ++p) buf_store<kStream>(u[p], rb, boff, 16 * brev(p, 4) * BSTEP);
+            } else {
+                // packed-real pass: a = Z[k1][col] (own), b = Z[255 - k1][256 - col] (256 - k1 in column 0), through the plane
+                R bx[16];
+#pragma unroll
+                for (int p = 0; p < 16; ++p) mine[brev(p, 4) * 16 * NC] = u[p].x;
+                lds_barrier();
+#pragma unroll
+                for (int p = 0; p < 16; ++p) bx[p] = theirs[(15 - brev(p, 4)) * 16 * NC];
+                lds_barrier();
+#pragma unroll
+                for (int p = 0; p < 16; ++p) mine[brev(p, 4) * 16 * NC] = u[p].y;
+                lds_barrier();
+                C wt = wt0;
+                asm volatile("" : "+v"(wt.x), "+v"(wt.y));
+#pragma unroll
+                for (int p = 0; p < 16; ++p) {
+                    const int k3 = brev(p, 4);
+                    const R by = theirs[(15 - k3) * 16 * NC];
+                    const C w = cmul(wt, C{(R) root64_re(2 * k3), (R) root64_im(2 * k3)});      // W_2L^{256 k1 + col}
+                    const R wqx = (R) 0.5 * w.y, wqy = (R) -0.5 * w.x;                            // -(i/2) W_2L^k
+                    const R ax = u[p].x, ay = u[p].y;
+                    const R sx = ax + bx[p], sy = ay - by, dx = ax - bx[p], dy = ay + by;
+                    C xk = C{(R) 0.5 * sx + (dx * wqx - dy * wqy), (R) 0.5 * sy + (dx * wqy + dy * wqx)};
+                    if (p == 0 && col0 && t == 0) {                 // k = 0: X[0], X[L] real (dsc_fft.h:221-225)
+                        xk = C{ax + ay, (R) 0};
+                        buf_store<BS>(C{ax - ay, (R) 0}, rb, L * CB, 0);
+                    }
+                    buf_store<BS>(xk, rb, boff, 16 * k3 * BSTEP);
+                }
+            }
+        } else {
+            // ================= column task backwards: bins -> A (scratch)
+            if constexpr (REAL) {
+                if (col0 && t == 0) { cur[0].y = (R) 0; }
+                R bx[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mine[e * 16 * NC] = cur[e].x;
+                lds_barrier();
+#pragma unroll
+                for (int e = 0; e < 16; ++e) bx[e] = theirs[(15 - e) * 16 * NC];
+                if (col0 && t == 0) bx[0] = cur_last.x;             // bin 0 pairs with bin L (real parts only, dsc_fft.h:227-228)
+                lds_barrier();
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mine[e * 16 * NC] = cur[e].y;
+                lds_barrier();
+                C wt = wt0;
+                asm volatile("" : "+v"(wt.x), "+v"(wt.y));
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    R by = theirs[(15 - e) * 16 * NC];
+                    if (e == 0 && col0 && t == 0) by = (R) 0;
+                    const C w = cmul(wt, C{(R) root64_re(2 * e), (R) root64_im(2 * e)});
+                    const R wqx = (R) 0.5 * w.y, wqy = (R) 0.5 * w.x;                             // (i/2) conj(W_2L^k)
+                    const R ax = cur[e].x, ay = cur[e].y;
+                    const R sx = ax + bx[e], sy = ay - by, dx = ax - bx[e], dy = ay + by;
+                    cur[e] = C{(R) 0.5 * sx + (dx * wqx - dy * wqy), (R) 0.5 * sy + (dx * wqy + dy * wqx)};
+                }
+                lds_barrier();
+            }
+            dft16<R, true>(cur);                                    // over k (k1 = t + 16 k) -> t' in cur[brev(t')]
+#pragma unroll
+            for (int tp = 1; tp < 16; ++tp) cur[brev(tp, 4)] = cmulc(cur[brev(tp, 4)], w256[tp * t]);
+            {
+                R *xw = plane + t * 16 * NC + ell;                  // plane[k1' = t][t'][ell]
+                const R *xr = plane + t * NC + ell;                 // thread (ell, t = t') reads every k1'
+#pragma unroll
+                for (int tp = 0; tp < 16; ++tp) xw[tp * NC] = cur[brev(tp, 4)].x;
+                lds_barrier();
+#pragma unroll
+                for (int k = 0; k < 16; ++k) u[k].x = xr[k * 16 * NC];
+                lds_barrier();
+#pragma unroll
+                for (int tp = 0; tp < 16; ++tp) xw[tp * NC] = cur[brev(tp, 4)].y;
+                lds_barrier();
+#pragma unroll
+                for (int k = 0; k < 16; ++k) u[k].y = xr[k * 16 * NC];
+            }
+            dft16<R, true>(u);                                      // over k1' -> i in u[brev(i)]: A[t + 16 i][col]
+            if (it > 0) {
+                spin(-1);
+                join();
+                if (broken) return;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) buf_store<kCached>(u[brev(i, 4)], rwork, woff, i * WSTEP);
+            arrive(true, slot);
+            spin(slot);
+            join();
+            if (broken) return;
+            // ================= row task backwards: A -> samples
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *) (ext_out + (size_t) row * ext_pitch_b), 0, ext_len_b, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = buf_load<kCoherent>(rwork, aoff, k * ASTEP, R{});
+            release_scratch();
+            four_step_twiddle16<R, true, false>(v, twL, j1r, rtau);
+            dft16<R, true>(v);                                      // over k -> s in v[brev(s)]
+#pragma unroll
+            for (int s = 1; s < 16; ++s) v[brev(s, 4)] = cmulc(v[brev(s, 4)], w256[s * rtau]);
+            R *wr = plane + rq * kPQ + rtau * kPK;
+            const R *rd = plane + wq * kPQ + ws;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) wr[s] = v[brev(s, 4)].x;
+            lds_barrier();
+#pragma unroll
+            for (int k = 0; k < 16; ++k) u[k].x = rd[k * kPK];
+            lds_barrier();
+#pragma unroll
+            for (int s = 0; s < 16; ++s) wr[s] = v[brev(s, 4)].y;
+            lds_barrier();
+#pragma unroll
+            for (int k = 0; k < 16; ++k) u[k].y = rd[k * kPK];
+            dft16<R, true>(u);                                      // over tau -> m in u[brev(m)]
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const C r = u[brev(m, 4)];
+                buf_store<kStream>(C{r.x * scale, r.y * scale}, ro, zoff, m * ZSTEP);
+            }
+        }
+        // the row after next was published in `slot` at the first barrier of this row
+        const int after = __builtin_amdgcn_readfirstlane(info[4 + slot]);
+        row = next; next = after;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) cur[m] = nxt[m];
+        cur_last = nxt_last;
+    }
+}
+
+struct launch_shape { int grid; };
+
+template<typename R, bool REAL, bool INV>
+bool launch_one(const void *in, void *out, long long rows, void *scratch, unsigned *host_error, const void *tw_full, const void *tw_real, double scale,
+                long long ext_pitch_b, int ext_len_b, long long bins_pitch, int bins_len, hipStream_t stream) {
+    using C = cpx<R>;
+    static int grids[64];                                       // resident launch size per device (0 = not asked yet, -1 = does not fit)
+    int dev = 0;
+    DSC_KERNEL_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return false;
+    if (grids[dev] == 0) {
+        int per_cu = 0, cus = 0;
+        DSC_KERNEL_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *) fused_l2_kernel<R, REAL, INV>, kNT, 0));
+        DSC_KERNEL_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        constexpr int want = sizeof(R) == 4 ? 3 : 1;            // workgroups per CU: six / two teams of 16 per XCD of 32 CUs
+        if (per_cu > want) per_cu = want;
+        int g = cus * per_cu;
+        g -= g % (8 * kTS);
+        if (g > 8 * kTS * kMaxTeams) g = 8 * kTS * kMaxTeams;
+        grids[dev] = g >= 8 * kTS ? g : -1;
+    }
+    if (grids[dev] < 0) return false;
+    fused_ctl *ctl = (fused_ctl *) scratch;
+    C *rowsbuf = (C *) ((char *) scratch + dsc_fft_fused_l2_ctl_bytes());
+    DSC_KERNEL_CHECK(hipMemsetAsync(ctl, 0, sizeof(fused_ctl), stream));
+    DSC_LAUNCH((fused_l2_kernel<R, REAL, INV>), dim3((unsigned) grids[dev]), dim3(kNT), 0, stream, INV ? (const char *) nullptr : (const char *) in,
+               INV ? (char *) out : (char *) nullptr, INV ? (const C *) in : (const C *) nullptr, INV ? (C *) nullptr : (C *) out, rowsbuf, ctl, host_error, (int) rows,
+               (const C *) tw_full, (const C *) tw_real, (R) scale, ext_pitch_b, ext_len_b, bins_pitch, bins_len);
+    return true;
+}
+
+}  // namespace
+
+size_t dsc_fft_fused_l2_ctl_bytes() { return (sizeof(fused_ctl) + 4095) / 4096 * 4096; }
+
+bool dsc_fft_fused_l2_supports(int L, bool single_precision) { return L == kL && single_precision; }
+
+// bytes of scratch a launch needs: the control block + one row of A per possible team
+size_t dsc_fft_fused_l2_scratch_bytes(int L, bool single_precision) {
+    return dsc_fft_fused_l2_ctl_bytes() + (size_t) 8 * kMaxTeams * L * (single_precision ? 8 : 16);
+}
+
+// Same arguments as dsc_launch_rfft_two_pass / dsc_launch_fft_two_pass (real = packed-real transform).  Returns false when the
+// launch cannot be made fully resident on this device (the caller falls back to the two-kernel route).
+bool dsc_launch_fft_fused_l2(const void *in, void *out, long long rows, int L, bool real, bool inverse, bool single_precision, void *scratch,
+                             unsigned *host_error, const void *tw_full, const void *tw_real, long long in_pitch, int in_len, hipStream_t stream) {
+    if (rows <= 0) return true;
+    if (L != kL || !single_precision || rows > 0x7fffff00) return false;
+    using R = float;
+    constexpr long long CBl = 2 * sizeof(R);
+    const double inv_scale = 1.0 / (double) L;                              // dsc_fft.h:232 (2 / 2n) and :168-175
+    if (real) {
+        if (!inverse) return launch_one<R, true, false>(in, out, rows, scratch, host_error, tw_full, tw_real, 1.0, in_pitch * (long long) sizeof(R), (int) (in_len * sizeof(R)),
+                                                        (long long) L + 1, L + 1, stream);
+        return launch_one<R, true, true>(in, out, rows, scratch, host_error, tw_full, tw_real, inv_scale, (long long) L * CBl, (int) (L * CBl), in_pitch, in_len, stream);
+    }
+    if (!inverse) return launch_one<R, false, false>(in, out, rows, scratch, host_error, tw_full, tw_full, 1.0, in_pitch * CBl, (int) (in_len * CBl), (long long) L, L, stream);
+    return launch_one<R, false, true>(in, out, rows, scratch, host_error, tw_full, tw_full, inv_scale, (long long) L * CBl, (int) (L * CBl), in_pitch, in_len, stream);
+}

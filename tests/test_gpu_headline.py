@@ -366,7 +366,8 @@ def test_two_pass_long_transforms(dsc, dt, n):
     for rows in (1, 5):
         x = rng.standard_normal((rows, n)).astype(dt)
         X = dsc.rfft(dsc.from_numpy(x))
-        assert dsc.last_fft_path() == 'r2c_2pass_regs'
+        fused = dt == np.float32 and n == 131072             # fft_xcd_fused.hip: one launch, intermediate in the XCD-local L2
+        assert dsc.last_fft_path() == ('r2c_fused_l2' if fused else 'r2c_2pass_regs')
         got = X.numpy()
         assert_close(got[rows - 1], port.rfft(x[rows - 1]), what=f'rfft {np.dtype(dt).name} n={n}')
         assert rel_l2(got, np.fft.rfft(x.astype(np.float64), axis=-1)) <= exact
@@ -375,7 +376,7 @@ def test_two_pass_long_transforms(dsc, dt, n):
         Xq[:, 0] += 2j                                     # ignored by dsc_fft.h:227-228
         Xq[:, -1] -= 3j
         back = dsc.irfft(dsc.from_numpy(Xq))
-        assert dsc.last_fft_path() == 'c2r_2pass_regs'
+        assert dsc.last_fft_path() == ('c2r_fused_l2' if fused else 'c2r_2pass_regs')
         bh = back.numpy()
         assert_close(bh[0], port.irfft(Xq[0]), what=f'irfft {np.dtype(dt).name} n={n}')
         assert rel_l2(bh, x) <= exact
@@ -447,6 +448,37 @@ def test_mid_sizes_padded_and_cropped(dsc, dt, n):
             assert_close(b.numpy()[0], port.irfft(Y[0], bins), what=f'irfft bins={bins} ls={ls}')
 
 
+def test_fused_l2_team_kernel_many_rows(dsc):
+    """fft_xcd_fused.hip (f32, 65536-point complex rows / real length 131072): more rows than teams, so that every team walks
+    several rows (claimed from the global counter, published at a team barrier) and the scratch rows are reused; all four
+    operators, every row compared.  A barrier that does not complete aborts at the synchronise."""
+    from oracle import port
+    rng = np.random.default_rng(131)
+    for rows in (47, 160):
+        x = rng.standard_normal((rows, 131072)).astype(np.float32)
+        X = dsc.rfft(dsc.from_numpy(x))
+        assert dsc.last_fft_path() == 'r2c_fused_l2'
+        want = port.rfft(x)
+        got = X.numpy()
+        for r in range(rows):
+            assert rel_l2(got[r], want[r]) <= 1e-6, ('rfft row', r, rows)
+        assert np.all(got[:, 0].imag == 0) and np.all(got[:, -1].imag == 0)
+        back = dsc.irfft(X).numpy()
+        assert dsc.last_fft_path() == 'c2r_fused_l2'
+        wb = port.irfft(want)
+        for r in range(rows):
+            assert rel_l2(back[r], wb[r]) <= 1e-6, ('irfft row', r, rows)
+        z = (rng.standard_normal((rows, 65536)) + 1j * rng.standard_normal((rows, 65536))).astype(np.complex64)
+        Z = dsc.fft(dsc.from_numpy(z))
+        assert dsc.last_fft_path() == 'c2c_fused_l2'
+        wz = port.fft(z)
+        zh = Z.numpy()
+        for r in range(rows):
+            assert rel_l2(zh[r], wz[r]) <= 1e-6, ('fft row', r, rows)
+        assert rel_l2(dsc.ifft(Z).numpy(), z) <= 1e-6
+    dsc.synchronize()
+
+
 @pytest.mark.parametrize('dt,n', [(np.float32, 131072), (np.float64, 65536), (np.float64, 262144)])
 def test_two_pass_padded_rows(dsc, dt, n):
     """Zero padded / cropped rows on the two-pass kernels (the row descriptors end at the last valid sample / bin)."""
@@ -456,13 +488,13 @@ def test_two_pass_padded_rows(dsc, dt, n):
     for rows, ls in ((3, n - 1), (2, n // 2 + 3), (2, n + 64)):
         x = rng.standard_normal((rows, ls)).astype(dt)
         got = dsc.rfft(dsc.from_numpy(x), n=n)
-        assert dsc.last_fft_path() == 'r2c_2pass_regs'
+        assert dsc.last_fft_path() == ('r2c_fused_l2' if dt == np.float32 else 'r2c_2pass_regs')
         assert_close(got.numpy()[rows - 1], port.rfft(x[rows - 1], n), what=f'padded 2-pass rfft n={n} ls={ls}')
     bins = n // 2 + 1
     for rows, lb in ((2, bins - 5), (3, bins + 9)):
         Y = (rng.standard_normal((rows, lb)) + 1j * rng.standard_normal((rows, lb))).astype(cdt)
         b = dsc.irfft(dsc.from_numpy(Y), n=bins)
-        assert dsc.last_fft_path() == 'c2r_2pass_regs'
+        assert dsc.last_fft_path() == ('c2r_fused_l2' if dt == np.float32 else 'c2r_2pass_regs')
         assert_close(b.numpy()[0], port.irfft(Y[0], bins), what=f'padded 2-pass irfft bins={bins} lb={lb}')
 
 
@@ -476,14 +508,15 @@ def test_two_pass_complex_transforms(dsc, dt, L):
     for rows, ls in ((1, L), (3, L), (2, L - 77), (2, L + 5)):
         z = (rng.standard_normal((rows, ls)) + 1j * rng.standard_normal((rows, ls))).astype(dt)
         Z = dsc.fft(dsc.from_numpy(z), n=L)
-        assert dsc.last_fft_path() == 'c2c_2pass_regs'
+        path = 'c2c_fused_l2' if (dt == np.complex64 and L == 65536) else 'c2c_2pass_regs'
+        assert dsc.last_fft_path() == path
         zh = Z.numpy()
         assert_close(zh[rows - 1], port.fft(z[rows - 1], L), what=f'fft L={L} ls={ls}')
         zp = np.zeros((rows, L), np.complex128)
         zp[:, :min(ls, L)] = z[:, :L]
         assert rel_l2(zh, np.fft.fft(zp, axis=-1)) <= tol
         back = dsc.ifft(Z)
-        assert dsc.last_fft_path() == 'c2c_2pass_regs'
+        assert dsc.last_fft_path() == path
         assert_close(back.numpy()[0], port.ifft(zh[0]), what=f'ifft L={L}')
         assert rel_l2(back.numpy(), zp) <= tol
 

@@ -1,0 +1,38 @@
+import sys, os, numpy as np
+sys.path.insert(0, '.')
+import dsc_amd as dsc
+from oracle import port
+from tests.helpers import rel_l2, max_rel
+dsc.init(4 << 30, 1 << 30)
+rng = np.random.default_rng(5)
+N = 131072
+ok = True
+for rows in (1, 3, 50, 150):
+    x = rng.standard_normal((rows, N)).astype(np.float32)
+    X = dsc.rfft(dsc.from_numpy(x)); p = dsc.last_fft_path()
+    want = port.rfft(x)
+    e = rel_l2(X.numpy(), want), max_rel(X.numpy(), want)
+    print('rfft', rows, p, e); ok &= e[0] < 1e-5
+    y = dsc.irfft(X); p = dsc.last_fft_path()
+    wy = port.irfft(want)
+    e = rel_l2(y.numpy(), wy), max_rel(y.numpy(), wy)
+    print('irfft', rows, p, e); ok &= e[0] < 1e-5
+    z = (rng.standard_normal((rows, 65536)) + 1j * rng.standard_normal((rows, 65536))).astype(np.complex64)
+    Z = dsc.fft(dsc.from_numpy(z)); p = dsc.last_fft_path()
+    wz = port.fft(z)
+    e = rel_l2(Z.numpy(), wz), max_rel(Z.numpy(), wz)
+    print('fft', rows, p, e); ok &= e[0] < 1e-5
+    zi = dsc.ifft(Z); p = dsc.last_fft_path()
+    e = rel_l2(zi.numpy(), port.ifft(wz)), 0
+    print('ifft', rows, p, e); ok &= e[0] < 1e-5
+# padding / cropping
+x = rng.standard_normal((5, 100000)).astype(np.float32)
+e = rel_l2(dsc.rfft(dsc.from_numpy(x), n=131072).numpy(), port.rfft(x, 131072)); print('rfft padded', dsc.last_fft_path(), e); ok &= e < 1e-5
+x = rng.standard_normal((5, 140000)).astype(np.float32)
+e = rel_l2(dsc.rfft(dsc.from_numpy(x), n=131072).numpy(), port.rfft(x, 131072)); print('rfft cropped', dsc.last_fft_path(), e); ok &= e < 1e-5
+Xs = (rng.standard_normal((4, 40000)) + 1j * rng.standard_normal((4, 40000))).astype(np.complex64)
+e = rel_l2(dsc.irfft(dsc.from_numpy(Xs), n=65537).numpy(), port.irfft(Xs, 65537)); print('irfft short', dsc.last_fft_path(), e); ok &= e < 1e-5
+z = (rng.standard_normal((4, 50000)) + 1j * rng.standard_normal((4, 50000))).astype(np.complex64)
+e = rel_l2(dsc.fft(dsc.from_numpy(z), n=65536).numpy(), port.fft(z, 65536)); print('fft padded', dsc.last_fft_path(), e); ok &= e < 1e-5
+dsc.synchronize()
+print('ALL OK' if ok else 'FAILED')

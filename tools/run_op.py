@@ -67,6 +67,7 @@ CASES['rfft_f64_4096'] = _rfft_case(4096, 65536, f64=True)
 CASES['rfft_f32_32'] = _rfft_case(32, 16777216)          # generic LDS kernel (complex length < 32)
 CASES['fft_c32_32768'] = _fft_case(32768, 8192)
 CASES['fft_c32_4096'] = _fft_case(4096, 65536)
+CASES['fft_c32_65536'] = _fft_case(65536, 4096)
 
 
 @case('filter64k')
