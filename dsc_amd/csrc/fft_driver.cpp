@@ -315,7 +315,7 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
         }
     }
 
-    // 65536-point complex rows (real length 131072), f32: one launch, the four-step intermediate stays in the XCD-local L2
+    // 65536-point complex rows (real length 131072): one launch, the four-step intermediate stays in the XCD-local L2
     // (fft_xcd_fused.hip)
     static const bool fused_off = getenv("DSC_NO_FUSED_L2") != nullptr;           // A/B aid
     if ((packed || j.mode == DSC_MODE_C2C) && inner == 1 && !fused_off && dsc_fft_fused_l2_supports(j.L, sp) &&

@@ -33,6 +33,9 @@ constexpr int kTS = 16;                   // workgroups per team = tasks per pha
 constexpr int kMaxTeams = 8;              // teams per XCD
 constexpr int kL = 65536;
 constexpr int kPQ = 276, kPK = 17;        // row-task exchange: line pitch (values), k2' pitch
+#ifndef DSC_FUSED_BINS_LOAD
+#define DSC_FUSED_BINS_LOAD kCached
+#endif
 #ifndef DSC_FUSED_BINS_STORE
 #define DSC_FUSED_BINS_STORE kCached
 #endif
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : 1)) void fused_l2_kernel
                                                                                long long ext_pitch_b, int ext_len_b, long long bins_pitch, int bins_len) {
     using C = cpx<R>;
     constexpr int CB = (int) sizeof(C), L = kL, NC = 16, H = 8;
-    constexpr int BL = REAL ? kCached : kStream;                    // spectrum rows of the real transforms are skewed: fft_r2c_2pass.hip
+    constexpr int BL = REAL ? DSC_FUSED_BINS_LOAD : kStream;                    // spectrum rows of the real transforms are skewed: fft_r2c_2pass.hip
     // ... and written in 64-B pieces that straddle sectors: with the default policy the pieces of the 16 column tasks of a row
     // (same XCD, same moment) meet in the L2 and leave as whole lines
     constexpr int BS = REAL ? DSC_FUSED_BINS_STORE : kStream;
@@ -463,7 +466,7 @@ bool launch_one(const void *in, void *out, long long rows, void *scratch, unsign
 
 size_t dsc_fft_fused_l2_ctl_bytes() { return (sizeof(fused_ctl) + 4095) / 4096 * 4096; }
 
-bool dsc_fft_fused_l2_supports(int L, bool single_precision) { return L == kL && single_precision; }
+bool dsc_fft_fused_l2_supports(int L, bool single_precision) { (void) single_precision; return L == kL; }
 
 // bytes of scratch a launch needs: the control block + one row of A per possible team
 size_t dsc_fft_fused_l2_scratch_bytes(int L, bool single_precision) {
@@ -472,11 +475,9 @@ size_t dsc_fft_fused_l2_scratch_bytes(int L, bool single_precision) {
 
 // Same arguments as dsc_launch_rfft_two_pass / dsc_launch_fft_two_pass (real = packed-real transform).  Returns false when the
 // launch cannot be made fully resident on this device (the caller falls back to the two-kernel route).
-bool dsc_launch_fft_fused_l2(const void *in, void *out, long long rows, int L, bool real, bool inverse, bool single_precision, void *scratch,
-                             unsigned *host_error, const void *tw_full, const void *tw_real, long long in_pitch, int in_len, hipStream_t stream) {
-    if (rows <= 0) return true;
-    if (L != kL || !single_precision || rows > 0x7fffff00) return false;
-    using R = float;
+template<typename R>
+static bool launch_any(const void *in, void *out, long long rows, int L, bool real, bool inverse, void *scratch, unsigned *host_error, const void *tw_full,
+                       const void *tw_real, long long in_pitch, int in_len, hipStream_t stream) {
     constexpr long long CBl = 2 * sizeof(R);
     const double inv_scale = 1.0 / (double) L;                              // dsc_fft.h:232 (2 / 2n) and :168-175
     if (real) {
@@ -486,4 +487,12 @@ bool dsc_launch_fft_fused_l2(const void *in, void *out, long long rows, int L, b
     }
     if (!inverse) return launch_one<R, false, false>(in, out, rows, scratch, host_error, tw_full, tw_full, 1.0, in_pitch * CBl, (int) (in_len * CBl), (long long) L, L, stream);
     return launch_one<R, false, true>(in, out, rows, scratch, host_error, tw_full, tw_full, inv_scale, (long long) L * CBl, (int) (L * CBl), in_pitch, in_len, stream);
+}
+
+bool dsc_launch_fft_fused_l2(const void *in, void *out, long long rows, int L, bool real, bool inverse, bool single_precision, void *scratch,
+                             unsigned *host_error, const void *tw_full, const void *tw_real, long long in_pitch, int in_len, hipStream_t stream) {
+    if (rows <= 0) return true;
+    if (L != kL || rows > 0x7fffff00) return false;
+    return single_precision ? launch_any<float>(in, out, rows, L, real, inverse, scratch, host_error, tw_full, tw_real, in_pitch, in_len, stream)
+                            : launch_any<double>(in, out, rows, L, real, inverse, scratch, host_error, tw_full, tw_real, in_pitch, in_len, stream);
 }

@@ -348,7 +348,7 @@ def test_full_size_f64_config5(dsc):
     assert np.max(np.abs(e_f - e_t) / e_t) < 1e-13
     idx = np.arange(rows) % 64
     assert rel_l2(Xh, Xh[idx] * (scale / scale[idx])[:, None]) <= 1e-15
-    del p
+    del p, tx                                          # three 4 GiB tensors do not fit the 12 GiB test arena next to cached plans
     back = dsc.irfft(X)
     assert dsc.last_fft_path() == 'c2r_2pass_regs'
     bh = back.numpy()
@@ -366,7 +366,7 @@ def test_two_pass_long_transforms(dsc, dt, n):
     for rows in (1, 5):
         x = rng.standard_normal((rows, n)).astype(dt)
         X = dsc.rfft(dsc.from_numpy(x))
-        fused = dt == np.float32 and n == 131072             # fft_xcd_fused.hip: one launch, intermediate in the XCD-local L2
+        fused = n == 131072                                  # fft_xcd_fused.hip: one launch, intermediate in the XCD-local L2
         assert dsc.last_fft_path() == ('r2c_fused_l2' if fused else 'r2c_2pass_regs')
         got = X.numpy()
         assert_close(got[rows - 1], port.rfft(x[rows - 1]), what=f'rfft {np.dtype(dt).name} n={n}')
@@ -449,7 +449,7 @@ def test_mid_sizes_padded_and_cropped(dsc, dt, n):
 
 
 def test_fused_l2_team_kernel_many_rows(dsc):
-    """fft_xcd_fused.hip (f32, 65536-point complex rows / real length 131072): more rows than teams, so that every team walks
+    """fft_xcd_fused.hip (65536-point complex rows / real length 131072, f32 and f64): more rows than teams, so that every team walks
     several rows (claimed from the global counter, published at a team barrier) and the scratch rows are reused; all four
     operators, every row compared.  A barrier that does not complete aborts at the synchronise."""
     from oracle import port
@@ -476,6 +476,19 @@ def test_fused_l2_team_kernel_many_rows(dsc):
         for r in range(rows):
             assert rel_l2(zh[r], wz[r]) <= 1e-6, ('fft row', r, rows)
         assert rel_l2(dsc.ifft(Z).numpy(), z) <= 1e-6
+    # f64: two teams per XCD, 1 MiB of intermediate per row
+    x = rng.standard_normal((90, 131072))
+    X = dsc.rfft(dsc.from_numpy(x))
+    assert dsc.last_fft_path() == 'r2c_fused_l2'
+    got, want = X.numpy(), port.rfft(x)
+    for r in range(90):
+        assert rel_l2(got[r], want[r]) <= 1e-14, ('f64 rfft row', r)
+    back = dsc.irfft(X).numpy()
+    assert dsc.last_fft_path() == 'c2r_fused_l2' and rel_l2(back, x) <= 1e-14
+    z = rng.standard_normal((70, 65536)) + 1j * rng.standard_normal((70, 65536))
+    Z = dsc.fft(dsc.from_numpy(z))
+    assert dsc.last_fft_path() == 'c2c_fused_l2'
+    assert rel_l2(Z.numpy(), port.fft(z)) <= 1e-14 and rel_l2(dsc.ifft(Z).numpy(), z) <= 1e-14
     dsc.synchronize()
 
 

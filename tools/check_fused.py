@@ -34,5 +34,15 @@ Xs = (rng.standard_normal((4, 40000)) + 1j * rng.standard_normal((4, 40000))).as
 e = rel_l2(dsc.irfft(dsc.from_numpy(Xs), n=65537).numpy(), port.irfft(Xs, 65537)); print('irfft short', dsc.last_fft_path(), e); ok &= e < 1e-5
 z = (rng.standard_normal((4, 50000)) + 1j * rng.standard_normal((4, 50000))).astype(np.complex64)
 e = rel_l2(dsc.fft(dsc.from_numpy(z), n=65536).numpy(), port.fft(z, 65536)); print('fft padded', dsc.last_fft_path(), e); ok &= e < 1e-5
+for rows in (2, 70):
+    x = rng.standard_normal((rows, N))
+    X = dsc.rfft(dsc.from_numpy(x)); p = dsc.last_fft_path(); want = port.rfft(x)
+    e = rel_l2(X.numpy(), want); print('f64 rfft', rows, p, e); ok &= e < 1e-14
+    y = dsc.irfft(X); p = dsc.last_fft_path()
+    e = rel_l2(y.numpy(), port.irfft(want)); print('f64 irfft', rows, p, e); ok &= e < 1e-14
+    z = rng.standard_normal((rows, 65536)) + 1j * rng.standard_normal((rows, 65536))
+    Z = dsc.fft(dsc.from_numpy(z)); p = dsc.last_fft_path(); wz = port.fft(z)
+    e = rel_l2(Z.numpy(), wz); print('f64 fft', rows, p, e); ok &= e < 1e-14
+    e = rel_l2(dsc.ifft(Z).numpy(), port.ifft(wz)); print('f64 ifft', rows, dsc.last_fft_path(), e); ok &= e < 1e-14
 dsc.synchronize()
 print('ALL OK' if ok else 'FAILED')

@@ -68,6 +68,9 @@ CASES['rfft_f32_32'] = _rfft_case(32, 16777216)          # generic LDS kernel (c
 CASES['fft_c32_32768'] = _fft_case(32768, 8192)
 CASES['fft_c32_4096'] = _fft_case(4096, 65536)
 CASES['fft_c32_65536'] = _fft_case(65536, 4096)
+CASES['fft_c64_65536'] = _fft_case(65536, 2048, f64=True)
+CASES['rfft_f64_131072'] = _rfft_case(131072, 2048, f64=True)
+CASES['irfft_f64_131072'] = _rfft_case(131072, 2048, f64=True, inverse=True)
 
 
 @case('filter64k')
