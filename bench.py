@@ -375,9 +375,12 @@ def main():
                     B.dsc_copy_from_host(ctx, piece, blk.ctypes.data, blk.nbytes)
                     B.dsc_tensor_free(ctx, piece)
                 ms_5 = timed(lambda: B.dsc_rfft(ctx, x5._c_ptr, X5._c_ptr, -1, -1), n=20)
-                ok['rfft_f64_262144'] = roofline_object('two_pass_rows_kernel + two_pass_cols_kernel', dsc.last_fft_path(),
-                                                        b5 * (n5 * 8 + (n5 // 2 + 1) * 16), ms_5, b5,
-                                                        f'1-D rfft f64 N={n5} batch={b5} (BASELINE configs[4]); two kernels, the time is their sum')
+                p5 = dsc.last_fft_path()
+                k5 = 'fused_l2_kernel' if p5.endswith('fused_l2') else 'two_pass_rows_kernel + two_pass_cols_kernel'
+                ok['rfft_f64_262144'] = roofline_object(k5, p5, b5 * (n5 * 8 + (n5 // 2 + 1) * 16), ms_5, b5,
+                                                        f'1-D rfft f64 N={n5} batch={b5} (BASELINE configs[4])' +
+                                                        ('; one launch, the four-step intermediate stays in the XCD-local L2' if k5 == 'fused_l2_kernel'
+                                                         else '; two kernels, the time is their sum'))
                 del x5, X5
             ok['note'] = 'same process, same HIP-event timer, this rank only, random inputs; not included in value'
             extra['other_kernels'] = ok

@@ -315,13 +315,14 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
         }
     }
 
-    // 65536-point complex rows (real length 131072): one launch, the four-step intermediate stays in the XCD-local L2
+    // 65536-point complex rows (real length 131072) and 131072-point f64 rows (config 5): one launch, the four-step intermediate stays in the XCD-local L2
     // (fft_xcd_fused.hip)
     static const bool fused_off = getenv("DSC_NO_FUSED_L2") != nullptr;           // A/B aid
-    if ((packed || j.mode == DSC_MODE_C2C) && inner == 1 && !fused_off && dsc_fft_fused_l2_supports(j.L, sp) &&
+    const bool fused_cplx = !packed;
+    const bool fused_fwd = fused_cplx ? !j.inverse : j.mode == DSC_MODE_R2C_PACKED;
+    if ((packed || j.mode == DSC_MODE_C2C) && inner == 1 && !fused_off && dsc_fft_fused_l2_supports(j.L, sp, packed, !fused_fwd) &&
         ctx->scratch.capacity() >= dsc_fft_fused_l2_scratch_bytes(j.L, sp) + DSC_DEVICE_ALIGN) {
-        const bool cplx = !packed;
-        const bool fwd = cplx ? !j.inverse : j.mode == DSC_MODE_R2C_PACKED;
+        const bool cplx = fused_cplx, fwd = fused_fwd;
         ctx->scratch.reset();
         char *blk = ctx->scratch.alloc(dsc_fft_fused_l2_scratch_bytes(j.L, sp));
         if (ctx->async_error == nullptr) {

@@ -29,9 +29,7 @@
 namespace {
 
 constexpr int kNT = 256;                  // threads per workgroup
-constexpr int kTS = 16;                   // workgroups per team = tasks per phase of a row
 constexpr int kMaxTeams = 8;              // teams per XCD
-constexpr int kL = 65536;
 constexpr int kPQ = 276, kPK = 17;        // row-task exchange: line pitch (values), k2' pitch
 #ifndef DSC_FUSED_BINS_LOAD
 #define DSC_FUSED_BINS_LOAD kCached
@@ -85,15 +83,15 @@ __device__ __forceinline__ void dft16(cpx<R> (&v)[16]) {
     x_stage<R, INV, 2>(v, std::make_integer_sequence<int, 8>{});
 }
 
-// W_L^{j1 (tau + 16 k)}, k = 4 a + b: W_L^{j1 tau} W_L^{64 j1 a} W_L^{16 j1 b}, three exact table values
-template<typename R, bool CONJ, bool BREV>
+// W_L^{j1 (tau + S k)}, k = 4 a + b: W_L^{j1 tau} W_L^{4 S j1 a} W_L^{S j1 b}, three exact table values (S = 16 or 32)
+template<typename R, bool CONJ, bool BREV, int S>
 __device__ __forceinline__ void four_step_twiddle16(cpx<R> (&v)[16], const cpx<R> *twL, int j1, int tau) {
     using C = cpx<R>;
     const C base = twL[j1 * tau];
-    const C b1 = twL[16 * j1], b2 = twL[32 * j1], b3 = twL[48 * j1];
+    const C b1 = twL[S * j1], b2 = twL[2 * S * j1], b3 = twL[3 * S * j1];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        const C bq = a == 0 ? base : cmul(base, twL[64 * j1 * a]);
+        const C bq = a == 0 ? base : cmul(base, twL[4 * S * j1 * a]);
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const C w = b == 0 ? bq : b == 1 ? cmul(bq, b1) : b == 2 ? cmul(bq, b2) : cmul(bq, b3);
@@ -107,23 +105,28 @@ __device__ __forceinline__ void four_step_twiddle16(cpx<R> (&v)[16], const cpx<R
 // REAL: dsc_rfft (forward) / dsc_irfft (INV).  !REAL: dsc_fft / dsc_ifft of complex rows.
 // ext  = the time-domain side (forward input, inverse output): row pitch ext_pitch_b bytes, ext_len_b valid bytes
 // bins = the frequency-domain side: row pitch bins_pitch bins, bins_len valid bins
-template<typename R, bool REAL, bool INV>
+// L2 = 256 or 512: the row-task transform length (L = 256 L2); TS = L2 / 16 workgroups per team.
+template<typename R, bool REAL, bool INV, int L2>
 __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : 1)) void fused_l2_kernel(const char *__restrict__ ext, char *__restrict__ ext_out,
                                                                                const cpx<R> *__restrict__ bins_in, cpx<R> *__restrict__ bins_out,
-                                                                               cpx<R> *scratch, fused_ctl *ctl, unsigned *host_error, int rows,
+                                                                               cpx<R> *scratch, fused_ctl *ctl, unsigned *host_error, int rows, int teams_cap,
                                                                                const cpx<R> *__restrict__ twL, const cpx<R> *__restrict__ tw_real, R scale,
                                                                                long long ext_pitch_b, int ext_len_b, long long bins_pitch, int bins_len) {
     using C = cpx<R>;
-    constexpr int CB = (int) sizeof(C), L = kL, NC = 16, H = 8;
+    constexpr int CB = (int) sizeof(C), L = 256 * L2, NC = 16, H = 8;
+    constexpr int kTS = L2 / 16;                                    // tasks per phase = workgroups per team
+    constexpr int LINES = 4096 / L2, TPL = L2 / 16;                 // row task: lines per task, threads per line
+    constexpr int kPQ5 = 532, kPK5 = 33;                            // row-task exchange of the 512-point lines
     constexpr int BL = REAL ? DSC_FUSED_BINS_LOAD : kStream;                    // spectrum rows of the real transforms are skewed: fft_r2c_2pass.hip
     // ... and written in 64-B pieces that straddle sectors: with the default policy the pieces of the 16 column tasks of a row
     // (same XCD, same moment) meet in the L2 and leave as whole lines
     constexpr int BS = REAL ? DSC_FUSED_BINS_STORE : kStream;
     __shared__ __attribute__((aligned(16))) R plane[16 * kPQ];      // row task: 16 lines x kPQ; column task: [k1][ell] 257 x 16
-    __shared__ C w256[256];
+    __shared__ C wtab[L2];                                          // W_L2^m
     __shared__ int info[8];
     const int tid = threadIdx.x;
-    w256[tid] = twL[tid * (L / 256)];
+    for (int i = tid; i < L2; i += kNT) wtab[i] = twL[i * 256];
+    constexpr int W1 = L2 / 256;                                    // W_256^m = wtab[W1 m]
 
     // ---- teams
     if (tid == 0) {
@@ -143,9 +146,9 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : 1)) void fused_l2_kernel
     // wave-uniform values read from LDS: readfirstlane keeps the descriptors built from them in SGPRs (no waterfall loops)
     const int arrival = __builtin_amdgcn_readfirstlane(info[1]);
     const int xcc = __builtin_amdgcn_readfirstlane(info[0]), team = arrival / kTS, rank = arrival % kTS;
-    if (team >= __builtin_amdgcn_readfirstlane(info[3]) || team >= kMaxTeams) return;               // workgroups that do not fill a team
+    if (team >= __builtin_amdgcn_readfirstlane(info[3]) || team >= kMaxTeams || team >= teams_cap) return;               // workgroups that do not fill a team
     unsigned *tb = &ctl->team[xcc * kMaxTeams + team][0];
-    C *scr = scratch + (size_t) (xcc * kMaxTeams + team) * L;
+    C *scr = scratch + (size_t) (xcc * teams_cap + team) * L;
     const __amdgpu_buffer_rsrc_t rwork = __builtin_amdgcn_make_buffer_rsrc((void *) scr, 0, L * CB, 0x00020000);
     unsigned target = 0;
     bool broken = false;
@@ -180,24 +183,26 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : 1)) void fused_l2_kernel
     // row task `rank`: lines j1 = 16 rank + q
     //   writer lanes tid = 16 s + q: hold z[j1 + 256 (s + 16 m)], m < 16   (pieces of 16 adjacent j1)
     //   reader lanes tid = 16 q + tau: hold A[j1][tau + 16 k], k < 16       (pieces of 16 adjacent k2)
-    const int wq = tid & 15, ws = tid >> 4;
-    const int rq = tid >> 4, rtau = tid & 15;
-    const int zoff = ((16 * rank + wq) + 256 * ws) * CB;       // REAL: z[j] = (x[2j], x[2j + 1])
-    const int aoff = ((16 * rank + rq) * 256 + rtau) * CB;
-    const int j1r = 16 * rank + rq;
-    constexpr int ZSTEP = 16 * 256 * CB, ASTEP = 16 * CB;
+    //   L2 = 512: 8 lines per task, 32 threads per line: writer tid = 8 s + q holds z[j1 + 256 (s + 32 m)]; reader tid = 32 q + tau,
+    //   tau = ka + 16 c, holds A[j1][tau + 32 kb] (the 32-point second stage = a radix-2 step folded into the LDS read + 16 points)
+    const int wq = tid % LINES, ws = tid / LINES;
+    const int rq = tid / TPL, rtau = tid % TPL;
+    const int zoff = ((LINES * rank + wq) + 256 * ws) * CB;    // REAL: z[j] = (x[2j], x[2j + 1])
+    const int aoff = ((LINES * rank + rq) * L2 + rtau) * CB;
+    const int j1r = LINES * rank + rq;
+    constexpr int ZSTEP = TPL * 256 * CB, ASTEP = TPL * CB;
     // column task `rank`: lanes tid = 16 t + ell: column ell (REAL: 8 columns 8 b + 1 .. 8 b + 8 and their mirrors; column 0
     // takes the place of the duplicate 128 in the last block), slice t of the 256-point axis (j1 = t + 16 i; k1 = t + 16 k)
     const int ell = tid & 15, t = tid >> 4;
     const bool last = rank == kTS - 1;
     const bool col0 = REAL && last && ell == H;
-    const int col = !REAL ? NC * rank + ell : col0 ? 0 : ell < H ? H * rank + 1 + ell : 256 - H - H * rank + (ell - H);
+    const int col = !REAL ? NC * rank + ell : col0 ? 0 : ell < H ? H * rank + 1 + ell : L2 - H - H * rank + (ell - H);
     const int ellp = (last && (ell == H - 1 || ell == H)) ? ell : NC - 1 - ell;
-    const int woff = (t * 256 + col) * CB, boff = (256 * t + col) * CB;     // bin 256 (t + 16 k) + col: + k * 16 BSTEP
-    constexpr int WSTEP = 16 * 256 * CB, BSTEP = 256 * CB;
+    const int woff = (t * L2 + col) * CB, boff = (L2 * t + col) * CB;       // bin L2 (t + 16 k) + col: + k * 16 BSTEP
+    constexpr int WSTEP = 16 * L2 * CB, BSTEP = L2 * CB;
     R *mine = plane + t * NC + ell;                                  // plane[k1 = t + 16 k][ell]: + k * 16 NC
     const R *theirs = plane + (15 - t) * NC + ellp + (col0 ? NC : 0);     // plane[255 - k1 (+ 1 in column 0)][ellp]: + (15 - k) * 16 NC
-    const C wt0 = REAL ? cmul(tw_real[col], tw_real[256 * t]) : C{(R) 1, (R) 0};      // W_2L^{256 t + col}
+    const C wt0 = REAL ? cmul(tw_real[col], tw_real[L2 * t]) : C{(R) 1, (R) 0};       // W_2L^{L2 t + col}
 
     int next = 0;
     C cur[16], nxt[16];
@@ -247,24 +252,48 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : 1)) void fused_l2_kernel
         C u[16], v[16];
         if constexpr (!INV) {
             // ================= row task: samples -> A (scratch)
-            dft16<R, false>(cur);                                   // over m -> k2' in cur[brev(k2')]
+            dft16<R, false>(cur);                                   // over m -> first index in cur[brev(.)]
 #pragma unroll
-            for (int k = 1; k < 16; ++k) cur[brev(k, 4)] = cmul(cur[brev(k, 4)], w256[ws * k]);
-            R *wr = plane + wq * kPQ + ws;
-            const R *rd = plane + rq * kPQ + rtau * kPK;
+            for (int k = 1; k < 16; ++k) cur[brev(k, 4)] = cmul(cur[brev(k, 4)], wtab[ws * k]);
+            if constexpr (L2 == 256) {
+                R *wr = plane + wq * kPQ + ws;
+                const R *rd = plane + rq * kPQ + rtau * kPK;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) wr[k * kPK] = cur[brev(k, 4)].x;
-            lds_barrier();
+                for (int k = 0; k < 16; ++k) wr[k * kPK] = cur[brev(k, 4)].x;
+                lds_barrier();
 #pragma unroll
-            for (int m = 0; m < 16; ++m) v[m].x = rd[m];
-            lds_barrier();
+                for (int m = 0; m < 16; ++m) v[m].x = rd[m];
+                lds_barrier();
 #pragma unroll
-            for (int k = 0; k < 16; ++k) wr[k * kPK] = cur[brev(k, 4)].y;
-            lds_barrier();
+                for (int k = 0; k < 16; ++k) wr[k * kPK] = cur[brev(k, 4)].y;
+                lds_barrier();
 #pragma unroll
-            for (int m = 0; m < 16; ++m) v[m].y = rd[m];
-            dft16<R, false>(v);                                     // over s -> k in v[brev(k)]: k2 = tau + 16 k
-            four_step_twiddle16<R, false, true>(v, twL, j1r, rtau);
+                for (int m = 0; m < 16; ++m) v[m].y = rd[m];
+            } else {
+                // 32-point second stage over s = s' + 16 c: y_c[s'] = (x[s'] +- x[s' + 16]) (W_32^{s'} for c = 1), then 16 points
+                // over s': bin kr = 2 kb + c.  The +- is taken while reading the exchange plane.
+                const bool hi = rtau >= 16;
+                R *wr = plane + wq * kPQ5 + ws;                     // plane[q][ka][s]
+                const R *rd = plane + rq * kPQ5 + (rtau & 15) * kPK5;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) wr[k * kPK5] = cur[brev(k, 4)].x;
+                lds_barrier();
+#pragma unroll
+                for (int m = 0; m < 16; ++m) { const R a = rd[m], b = rd[m + 16]; v[m].x = hi ? a - b : a + b; }
+                lds_barrier();
+#pragma unroll
+                for (int k = 0; k < 16; ++k) wr[k * kPK5] = cur[brev(k, 4)].y;
+                lds_barrier();
+#pragma unroll
+                for (int m = 0; m < 16; ++m) { const R a = rd[m], b = rd[m + 16]; v[m].y = hi ? a - b : a + b; }
+#pragma unroll
+                for (int m = 1; m < 16; ++m) {
+                    const C w = C{hi ? (R) root64_re(2 * m) : (R) 1, hi ? (R) root64_im(2 * m) : (R) 0};      // W_32^{s'}
+                    v[m] = cmul(v[m], w);
+                }
+            }
+            dft16<R, false>(v);                                     // over s (s') -> k in v[brev(k)]: k2 = tau + TPL k
+            four_step_twiddle16<R, false, true, TPL>(v, twL, j1r, rtau);
             if (it > 0) {                                           // the team has finished READING the previous row's A
                 spin(-1);
                 join();
@@ -283,7 +312,7 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : 1)) void fused_l2_kernel
             release_scratch();
             dft16<R, false>(v);                                     // over i -> k1' in v[brev(k1')]
 #pragma unroll
-            for (int k = 1; k < 16; ++k) v[brev(k, 4)] = cmul(v[brev(k, 4)], w256[t * k]);
+            for (int k = 1; k < 16; ++k) v[brev(k, 4)] = cmul(v[brev(k, 4)], wtab[W1 * t * k]);
             {
                 R *xw = plane + t * NC + ell;                       // plane[k1'][t][ell]
                 const R *xr = plane + t * 16 * NC + ell;            // thread (ell, t = k1') reads every slice t'
@@ -365,7 +394,7 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : 1)) void fused_l2_kernel
             }
             dft16<R, true>(cur);                                    // over k (k1 = t + 16 k) -> t' in cur[brev(t')]
 #pragma unroll
-            for (int tp = 1; tp < 16; ++tp) cur[brev(tp, 4)] = cmulc(cur[brev(tp, 4)], w256[tp * t]);
+            for (int tp = 1; tp < 16; ++tp) cur[brev(tp, 4)] = cmulc(cur[brev(tp, 4)], wtab[W1 * tp * t]);
             {
                 R *xw = plane + t * 16 * NC + ell;                  // plane[k1' = t][t'][ell]
                 const R *xr = plane + t * NC + ell;                 // thread (ell, t = t') reads every k1'
@@ -398,23 +427,49 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : 1)) void fused_l2_kernel
 #pragma unroll
             for (int k = 0; k < 16; ++k) v[k] = buf_load<kCoherent>(rwork, aoff, k * ASTEP, R{});
             release_scratch();
-            four_step_twiddle16<R, true, false>(v, twL, j1r, rtau);
-            dft16<R, true>(v);                                      // over k -> s in v[brev(s)]
+            four_step_twiddle16<R, true, false, TPL>(v, twL, j1r, rtau);
+            dft16<R, true>(v);                                      // over k -> s (s') in v[brev(.)]
+            if constexpr (L2 == 256) {
 #pragma unroll
-            for (int s = 1; s < 16; ++s) v[brev(s, 4)] = cmulc(v[brev(s, 4)], w256[s * rtau]);
-            R *wr = plane + rq * kPQ + rtau * kPK;
-            const R *rd = plane + wq * kPQ + ws;
+                for (int s = 1; s < 16; ++s) v[brev(s, 4)] = cmulc(v[brev(s, 4)], wtab[s * rtau]);
+                R *wr = plane + rq * kPQ + rtau * kPK;
+                const R *rd = plane + wq * kPQ + ws;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) wr[s] = v[brev(s, 4)].x;
-            lds_barrier();
+                for (int s = 0; s < 16; ++s) wr[s] = v[brev(s, 4)].x;
+                lds_barrier();
 #pragma unroll
-            for (int k = 0; k < 16; ++k) u[k].x = rd[k * kPK];
-            lds_barrier();
+                for (int k = 0; k < 16; ++k) u[k].x = rd[k * kPK];
+                lds_barrier();
 #pragma unroll
-            for (int s = 0; s < 16; ++s) wr[s] = v[brev(s, 4)].y;
-            lds_barrier();
+                for (int s = 0; s < 16; ++s) wr[s] = v[brev(s, 4)].y;
+                lds_barrier();
 #pragma unroll
-            for (int k = 0; k < 16; ++k) u[k].y = rd[k * kPK];
+                for (int k = 0; k < 16; ++k) u[k].y = rd[k * kPK];
+            } else {
+                // x[s'] = y_0[s'] + conj(W_32^{s'}) y_1[s'], x[s' + 16] = y_0[s'] - ...: this lane holds y_c, the +- is taken by the reader
+                const bool hi = rtau >= 16;
+#pragma unroll
+                for (int m = 1; m < 16; ++m) {
+                    const C w = C{hi ? (R) root64_re(2 * m) : (R) 1, hi ? (R) root64_im(2 * m) : (R) 0};
+                    v[brev(m, 4)] = cmulc(v[brev(m, 4)], w);
+                }
+                R *wr = plane + rq * kPQ5 + (rtau & 15) * kPK5 + (hi ? 16 : 0);      // plane[q][ka][s' + 16 c]
+                const R *rd = plane + wq * kPQ5 + (ws & 15);
+                const bool up = ws >= 16;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) wr[m] = v[brev(m, 4)].x;
+                lds_barrier();
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { const R p0 = rd[k * kPK5], p1 = rd[k * kPK5 + 16]; u[k].x = up ? p0 - p1 : p0 + p1; }
+                lds_barrier();
+#pragma unroll
+                for (int m = 0; m < 16; ++m) wr[m] = v[brev(m, 4)].y;
+                lds_barrier();
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { const R p0 = rd[k * kPK5], p1 = rd[k * kPK5 + 16]; u[k].y = up ? p0 - p1 : p0 + p1; }
+#pragma unroll
+                for (int k = 1; k < 16; ++k) u[k] = cmulc(u[k], wtab[ws * k]);       // conj W_512^{s ka}
+            }
             dft16<R, true>(u);                                      // over tau -> m in u[brev(m)]
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
@@ -431,34 +486,38 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : 1)) void fused_l2_kernel
     }
 }
 
-struct launch_shape { int grid; };
+// workgroups per CU the launch asks for, and the rows of scratch that implies (one per possible team, + 1 per XCD of slack for an
+// uneven dispatch).  f32 rows of 512 KiB: six teams per XCD (3 MiB of its 4 MiB L2); f64 1 MiB: two; 2 MiB (L2 = 512, f64): one.
+constexpr int wg_per_cu(bool single_precision) { return single_precision ? 3 : 1; }
+constexpr int teams_cap_of(int L, bool single_precision) { return wg_per_cu(single_precision) * 32 / (L / 256 / 16) + 1; }
 
-template<typename R, bool REAL, bool INV>
+template<typename R, bool REAL, bool INV, int L2>
 bool launch_one(const void *in, void *out, long long rows, void *scratch, unsigned *host_error, const void *tw_full, const void *tw_real, double scale,
                 long long ext_pitch_b, int ext_len_b, long long bins_pitch, int bins_len, hipStream_t stream) {
     using C = cpx<R>;
+    constexpr int TS = L2 / 16, L = 256 * L2;
+    constexpr int cap = teams_cap_of(L, sizeof(R) == 4);
     static int grids[64];                                       // resident launch size per device (0 = not asked yet, -1 = does not fit)
     int dev = 0;
     DSC_KERNEL_CHECK(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return false;
     if (grids[dev] == 0) {
         int per_cu = 0, cus = 0;
-        DSC_KERNEL_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *) fused_l2_kernel<R, REAL, INV>, kNT, 0));
+        DSC_KERNEL_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *) fused_l2_kernel<R, REAL, INV, L2>, kNT, 0));
         DSC_KERNEL_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        constexpr int want = sizeof(R) == 4 ? 3 : 1;            // workgroups per CU: six / two teams of 16 per XCD of 32 CUs
-        if (per_cu > want) per_cu = want;
+        if (per_cu > wg_per_cu(sizeof(R) == 4)) per_cu = wg_per_cu(sizeof(R) == 4);
         int g = cus * per_cu;
-        g -= g % (8 * kTS);
-        if (g > 8 * kTS * kMaxTeams) g = 8 * kTS * kMaxTeams;
-        grids[dev] = g >= 8 * kTS ? g : -1;
+        g -= g % (8 * TS);
+        if (g > 8 * TS * (cap - 1)) g = 8 * TS * (cap - 1);
+        grids[dev] = g >= 8 * TS ? g : -1;
     }
     if (grids[dev] < 0) return false;
     fused_ctl *ctl = (fused_ctl *) scratch;
     C *rowsbuf = (C *) ((char *) scratch + dsc_fft_fused_l2_ctl_bytes());
     DSC_KERNEL_CHECK(hipMemsetAsync(ctl, 0, sizeof(fused_ctl), stream));
-    DSC_LAUNCH((fused_l2_kernel<R, REAL, INV>), dim3((unsigned) grids[dev]), dim3(kNT), 0, stream, INV ? (const char *) nullptr : (const char *) in,
+    DSC_LAUNCH((fused_l2_kernel<R, REAL, INV, L2>), dim3((unsigned) grids[dev]), dim3(kNT), 0, stream, INV ? (const char *) nullptr : (const char *) in,
                INV ? (char *) out : (char *) nullptr, INV ? (const C *) in : (const C *) nullptr, INV ? (C *) nullptr : (C *) out, rowsbuf, ctl, host_error, (int) rows,
-               (const C *) tw_full, (const C *) tw_real, (R) scale, ext_pitch_b, ext_len_b, bins_pitch, bins_len);
+               cap, (const C *) tw_full, (const C *) tw_real, (R) scale, ext_pitch_b, ext_len_b, bins_pitch, bins_len);
     return true;
 }
 
@@ -466,33 +525,42 @@ bool launch_one(const void *in, void *out, long long rows, void *scratch, unsign
 
 size_t dsc_fft_fused_l2_ctl_bytes() { return (sizeof(fused_ctl) + 4095) / 4096 * 4096; }
 
-bool dsc_fft_fused_l2_supports(int L, bool single_precision) { (void) single_precision; return L == kL; }
+// complex length 65536 (256 x 256), f32 and f64; 131072 (256 x 512) in f64 = BASELINE config 5 (its 512-point row tasks read
+// 8 adjacent lines: 128-B pieces in f64, only 64 B in f32, which stays on the two-kernel route)
+// The inverse REAL transform of 131072 bins is the one case measured slower than the two-kernel route (4.16 vs 3.82 ms: one team
+// per XCD, nothing overlaps its longer first phase) and stays there.
+bool dsc_fft_fused_l2_supports(int L, bool single_precision, bool real, bool inverse) {
+    if (L == 65536) return true;
+    return L == 131072 && !single_precision && !(real && inverse);
+}
 
 // bytes of scratch a launch needs: the control block + one row of A per possible team
 size_t dsc_fft_fused_l2_scratch_bytes(int L, bool single_precision) {
-    return dsc_fft_fused_l2_ctl_bytes() + (size_t) 8 * kMaxTeams * L * (single_precision ? 8 : 16);
+    return dsc_fft_fused_l2_ctl_bytes() + (size_t) 8 * teams_cap_of(L, single_precision) * L * (single_precision ? 8 : 16);
+}
+
+template<typename R, int L2>
+static bool launch_any(const void *in, void *out, long long rows, bool real, bool inverse, void *scratch, unsigned *host_error, const void *tw_full,
+                       const void *tw_real, long long in_pitch, int in_len, hipStream_t stream) {
+    constexpr long long CBl = 2 * sizeof(R);
+    constexpr int L = 256 * L2;
+    const double inv_scale = 1.0 / (double) L;                              // dsc_fft.h:232 (2 / 2n) and :168-175
+    if (real) {
+        if (!inverse) return launch_one<R, true, false, L2>(in, out, rows, scratch, host_error, tw_full, tw_real, 1.0, in_pitch * (long long) sizeof(R), (int) (in_len * sizeof(R)),
+                                                            (long long) L + 1, L + 1, stream);
+        return launch_one<R, true, true, L2>(in, out, rows, scratch, host_error, tw_full, tw_real, inv_scale, (long long) L * CBl, (int) (L * CBl), in_pitch, in_len, stream);
+    }
+    if (!inverse) return launch_one<R, false, false, L2>(in, out, rows, scratch, host_error, tw_full, tw_full, 1.0, in_pitch * CBl, (int) (in_len * CBl), (long long) L, L, stream);
+    return launch_one<R, false, true, L2>(in, out, rows, scratch, host_error, tw_full, tw_full, inv_scale, (long long) L * CBl, (int) (L * CBl), in_pitch, in_len, stream);
 }
 
 // Same arguments as dsc_launch_rfft_two_pass / dsc_launch_fft_two_pass (real = packed-real transform).  Returns false when the
 // launch cannot be made fully resident on this device (the caller falls back to the two-kernel route).
-template<typename R>
-static bool launch_any(const void *in, void *out, long long rows, int L, bool real, bool inverse, void *scratch, unsigned *host_error, const void *tw_full,
-                       const void *tw_real, long long in_pitch, int in_len, hipStream_t stream) {
-    constexpr long long CBl = 2 * sizeof(R);
-    const double inv_scale = 1.0 / (double) L;                              // dsc_fft.h:232 (2 / 2n) and :168-175
-    if (real) {
-        if (!inverse) return launch_one<R, true, false>(in, out, rows, scratch, host_error, tw_full, tw_real, 1.0, in_pitch * (long long) sizeof(R), (int) (in_len * sizeof(R)),
-                                                        (long long) L + 1, L + 1, stream);
-        return launch_one<R, true, true>(in, out, rows, scratch, host_error, tw_full, tw_real, inv_scale, (long long) L * CBl, (int) (L * CBl), in_pitch, in_len, stream);
-    }
-    if (!inverse) return launch_one<R, false, false>(in, out, rows, scratch, host_error, tw_full, tw_full, 1.0, in_pitch * CBl, (int) (in_len * CBl), (long long) L, L, stream);
-    return launch_one<R, false, true>(in, out, rows, scratch, host_error, tw_full, tw_full, inv_scale, (long long) L * CBl, (int) (L * CBl), in_pitch, in_len, stream);
-}
-
 bool dsc_launch_fft_fused_l2(const void *in, void *out, long long rows, int L, bool real, bool inverse, bool single_precision, void *scratch,
                              unsigned *host_error, const void *tw_full, const void *tw_real, long long in_pitch, int in_len, hipStream_t stream) {
     if (rows <= 0) return true;
-    if (L != kL || rows > 0x7fffff00) return false;
-    return single_precision ? launch_any<float>(in, out, rows, L, real, inverse, scratch, host_error, tw_full, tw_real, in_pitch, in_len, stream)
-                            : launch_any<double>(in, out, rows, L, real, inverse, scratch, host_error, tw_full, tw_real, in_pitch, in_len, stream);
+    if (!dsc_fft_fused_l2_supports(L, single_precision, real, inverse) || rows > 0x7fffff00) return false;
+    if (L == 131072) return launch_any<double, 512>(in, out, rows, real, inverse, scratch, host_error, tw_full, tw_real, in_pitch, in_len, stream);
+    return single_precision ? launch_any<float, 256>(in, out, rows, real, inverse, scratch, host_error, tw_full, tw_real, in_pitch, in_len, stream)
+                            : launch_any<double, 256>(in, out, rows, real, inverse, scratch, host_error, tw_full, tw_real, in_pitch, in_len, stream);
 }

@@ -44,5 +44,19 @@ for rows in (2, 70):
     Z = dsc.fft(dsc.from_numpy(z)); p = dsc.last_fft_path(); wz = port.fft(z)
     e = rel_l2(Z.numpy(), wz); print('f64 fft', rows, p, e); ok &= e < 1e-14
     e = rel_l2(dsc.ifft(Z).numpy(), port.ifft(wz)); print('f64 ifft', rows, dsc.last_fft_path(), e); ok &= e < 1e-14
+for rows in (1, 3, 40):
+    x = rng.standard_normal((rows, 262144))
+    X = dsc.rfft(dsc.from_numpy(x)); p = dsc.last_fft_path(); want = port.rfft(x)
+    e = rel_l2(X.numpy(), want); print('f64 rfft 262144', rows, p, e); ok &= e < 1e-14
+    y = dsc.irfft(X); p = dsc.last_fft_path()
+    e = rel_l2(y.numpy(), port.irfft(want)); print('f64 irfft 262144', rows, p, e); ok &= e < 1e-14
+    z = rng.standard_normal((rows, 131072)) + 1j * rng.standard_normal((rows, 131072))
+    Z = dsc.fft(dsc.from_numpy(z)); p = dsc.last_fft_path(); wz = port.fft(z)
+    e = rel_l2(Z.numpy(), wz); print('f64 fft 131072', rows, p, e); ok &= e < 1e-14
+    e = rel_l2(dsc.ifft(Z).numpy(), port.ifft(wz)); print('f64 ifft 131072', rows, dsc.last_fft_path(), e); ok &= e < 1e-14
+x = rng.standard_normal((3, 200000))
+e = rel_l2(dsc.rfft(dsc.from_numpy(x), n=262144).numpy(), port.rfft(x, 262144)); print('f64 rfft padded', dsc.last_fft_path(), e); ok &= e < 1e-14
+Xs = rng.standard_normal((2, 100000)) + 1j * rng.standard_normal((2, 100000))
+e = rel_l2(dsc.irfft(dsc.from_numpy(Xs), n=131073).numpy(), port.irfft(Xs, 131073)); print('f64 irfft short', dsc.last_fft_path(), e); ok &= e < 1e-14
 dsc.synchronize()
 print('ALL OK' if ok else 'FAILED')

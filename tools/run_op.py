@@ -36,7 +36,7 @@ def _rfft_case(n, batch, f64=False, inverse=False):
     return make
 
 
-def _fft_case(n, batch, f64=False):
+def _fft_case(n, batch, f64=False, inverse=False):
     def make(dsc, B, ctx, np):
         cdt = dsc.Dtype.C64 if f64 else dsc.Dtype.C32
         npc = np.complex128 if f64 else np.complex64
@@ -45,6 +45,8 @@ def _fft_case(n, batch, f64=False):
         x = dsc.from_numpy(np.tile(blk, (batch // blk.shape[0], 1)))
         X = dsc.empty((batch, n), cdt)
         es = 16 if f64 else 8
+        if inverse:
+            return (lambda: B.dsc_ifft(ctx, x._c_ptr, X._c_ptr, -1, -1)), 2 * batch * n * es, (x, X)
         return (lambda: B.dsc_fft(ctx, x._c_ptr, X._c_ptr, -1, -1)), 2 * batch * n * es, (x, X)
     return make
 
@@ -69,6 +71,9 @@ CASES['fft_c32_32768'] = _fft_case(32768, 8192)
 CASES['fft_c32_4096'] = _fft_case(4096, 65536)
 CASES['fft_c32_65536'] = _fft_case(65536, 4096)
 CASES['fft_c64_65536'] = _fft_case(65536, 2048, f64=True)
+CASES['fft_c64_131072'] = _fft_case(131072, 2048, f64=True)
+CASES['ifft_c64_131072'] = _fft_case(131072, 2048, f64=True, inverse=True)
+CASES['ifft_c32_65536'] = _fft_case(65536, 4096, inverse=True)
 CASES['rfft_f64_131072'] = _rfft_case(131072, 2048, f64=True)
 CASES['irfft_f64_131072'] = _rfft_case(131072, 2048, f64=True, inverse=True)
 
