@@ -60,6 +60,16 @@ __device__ __forceinline__ void l2_store(unsigned *p, unsigned v) {
     asm volatile("global_store_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : : "v"(p), "v"(v) : "memory");
 }
 
+// 128-bit stores (c64) at two or more waves per SIMD: the data registers of a buffer_store_dwordx4 must not be rewritten by the very
+// next VALU instruction — observed on gfx950 as the last quad of each 16-lane row storing the NEXT value (tools/stress_fused.py:
+// 16 elements of one store instruction wrong in ~1 row of 100, only with f64 data at occupancy 2).  hipcc pads this hazard only for a
+// literal soffset; two wait states after every such store cost nothing here.
+template<int POL, typename R>
+__device__ __forceinline__ void st(cpx<R> a, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    buf_store<POL>(a, r, voff, soff);
+    if constexpr (sizeof(R) == 8) asm volatile("s_nop 1");
+}
+
 template<typename R, bool INV, int M, int G, int... K>
 __device__ __forceinline__ void x_group(cpx<R> (&v)[16], std::integer_sequence<int, K...>) {
     (([&] {
@@ -107,7 +117,7 @@ __device__ __forceinline__ void four_step_twiddle16(cpx<R> (&v)[16], const cpx<R
 // bins = the frequency-domain side: row pitch bins_pitch bins, bins_len valid bins
 // L2 = 256 or 512: the row-task transform length (L = 256 L2); TS = L2 / 16 workgroups per team.
 template<typename R, bool REAL, bool INV, int L2>
-__global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : 1)) void fused_l2_kernel(const char *__restrict__ ext, char *__restrict__ ext_out,
+__global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : L2 == 512 ? 2 : 1)) void fused_l2_kernel(const char *__restrict__ ext, char *__restrict__ ext_out,
                                                                                const cpx<R> *__restrict__ bins_in, cpx<R> *__restrict__ bins_out,
                                                                                cpx<R> *scratch, fused_ctl *ctl, unsigned *host_error, int rows, int teams_cap,
                                                                                const cpx<R> *__restrict__ twL, const cpx<R> *__restrict__ tw_real, R scale,
@@ -147,8 +157,17 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : 1)) void fused_l2_kernel
     const int arrival = __builtin_amdgcn_readfirstlane(info[1]);
     const int xcc = __builtin_amdgcn_readfirstlane(info[0]), team = arrival / kTS, rank = arrival % kTS;
     if (team >= __builtin_amdgcn_readfirstlane(info[3]) || team >= kMaxTeams || team >= teams_cap) return;               // workgroups that do not fill a team
+    // Counters of a team (one 256-B block in the XCD's L2): [0] arrivals at "A is written", [4] / [5] published rows, [8] arrivals
+    // at "A has been read", [12] members that have left.
+    // PAIRED (2 MiB of A per row: the L2 has room for ONE): teams 2p and 2p + 1 of an XCD share one scratch row and take turns —
+    // a team may write A only once its partner has read its own; while one team is in its write -> barrier -> read window the
+    // other computes its column task and the next row task.  Two workgroups per CU, one row of A live per XCD.
+    constexpr bool PAIRED = L2 == 512;
     unsigned *tb = &ctl->team[xcc * kMaxTeams + team][0];
-    C *scr = scratch + (size_t) (xcc * teams_cap + team) * L;
+    const int n_teams = __builtin_amdgcn_readfirstlane(info[3]) < teams_cap ? __builtin_amdgcn_readfirstlane(info[3]) : teams_cap;
+    const bool has_partner = PAIRED && (team ^ 1) < n_teams && (team ^ 1) < kMaxTeams;
+    unsigned *pb = &ctl->team[xcc * kMaxTeams + (team ^ 1)][0];
+    C *scr = scratch + (size_t) (xcc * teams_cap + (PAIRED ? team >> 1 : team)) * L;
     const __amdgpu_buffer_rsrc_t rwork = __builtin_amdgcn_make_buffer_rsrc((void *) scr, 0, L * CB, 0x00020000);
     unsigned target = 0;
     bool broken = false;
@@ -163,6 +182,28 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : 1)) void fused_l2_kernel
             if (rank == 0 && slot >= 0) l2_store(tb + 4 + slot, atomicAdd(&ctl->row_counter, 1u));
             l2_add(tb, 1u);
         }
+    };
+    // "this workgroup has read its part of A" (counter [8]); and the wait before A is written again: until `need` such arrivals
+    // at counter `c`, or until every member of that team has left (counter c[4] = [12])
+    auto arrive_read = [&]() {
+        lds_barrier();
+        if (tid == kNT - 1) l2_add(tb + 8, 1u);
+    };
+    auto wait_read = [&](unsigned *c, unsigned need) {
+        if (tid == kNT - 1) {
+            unsigned spins = 0;
+            while ((int) (l2_fetch_add(c, 0u) - need) < 0) {
+                if (l2_fetch_add(c + 4, 0u) >= (unsigned) kTS) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > kSpinLimit) { __hip_atomic_store(host_error, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); info[2] = 1; break; }
+            }
+        }
+        lds_barrier();
+        broken = info[2] != 0;
+    };
+    auto leave = [&]() {
+        lds_barrier();
+        if (tid == kNT - 1) l2_add(tb + 12, 1u);
     };
     auto spin = [&](int slot) {
         if (tid == kNT - 1) {
@@ -190,6 +231,8 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : 1)) void fused_l2_kernel
     const int zoff = ((LINES * rank + wq) + 256 * ws) * CB;    // REAL: z[j] = (x[2j], x[2j + 1])
     const int aoff = ((LINES * rank + rq) * L2 + rtau) * CB;
     const int j1r = LINES * rank + rq;
+    // PAIRED: the seven table values of the inter-pass twiddle are re-read per row (L2 hits) instead of living in 28 registers
+    auto opaque_j1 = [&]() { int j = j1r; if constexpr (PAIRED) asm volatile("" : "+v"(j)); return j; };
     constexpr int ZSTEP = TPL * 256 * CB, ASTEP = TPL * CB;
     // column task `rank`: lanes tid = 16 t + ell: column ell (REAL: 8 columns 8 b + 1 .. 8 b + 8 and their mirrors; column 0
     // takes the place of the duplicate 128 in the last block), slice t of the 256-point axis (j1 = t + 16 i; k1 = t + 16 k)
@@ -205,8 +248,8 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : 1)) void fused_l2_kernel
     const C wt0 = REAL ? cmul(tw_real[col], tw_real[L2 * t]) : C{(R) 1, (R) 0};       // W_2L^{L2 t + col}
 
     int next = 0;
-    C cur[16], nxt[16];
-    C cur_last = C{(R) 0, (R) 0}, nxt_last = C{(R) 0, (R) 0};
+    C cur[16];                                                      // the samples (bins) of the current row; refilled with the next row's
+    C cur_last = C{(R) 0, (R) 0};                                   // while the second task of the current one runs (it is dead by then)
     auto request = [&](C (&dst)[16], C &dlast, int row) {
         if constexpr (!INV) {
             const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *) (ext + (size_t) row * ext_pitch_b), 0, ext_len_b, 0x00020000);
@@ -224,12 +267,22 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : 1)) void fused_l2_kernel
     // the 16 or 17 loads of the next row requested right behind them), WAIT only before the next row's A is stored — the
     // barrier's latency hides behind the column task and the next row task.
     auto release_scratch = [&]() {
-        // (the fences keep the compiler from moving the request ahead of the reads of A: the count below relies on the order)
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        if (next < rows) { request(nxt, nxt_last, next); __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
-        else             { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-        arrive(false, -1);
+        if constexpr (PAIRED) {
+            // the partner may overwrite A as soon as this team has arrived: wait for the reads themselves, then ask for the next row
+            // (the next row is requested in the middle of the second task, once the registers that held A are free: at two
+            // workgroups per CU there are 256 per lane)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            arrive_read();
+        } else {
+            // the request goes out right behind the reads of A, which return first (in order): 16 (17) loads may stay in flight.
+            // (Relies on no other vector memory instruction in between — the kernels of this form have no spills; the fences keep
+            // the compiler from moving the request ahead of the reads.)
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (next < rows) { request(cur, cur_last, next); __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+            else             { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            arrive_read();
+        }
     };
 
     // ---- the first two rows of this team
@@ -247,7 +300,14 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : 1)) void fused_l2_kernel
     next = __builtin_amdgcn_readfirstlane(info[5]);
     if (row < rows) request(cur, cur_last, row);
 
+#ifdef DSC_FUSED_PROFILE
+    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pl = wall_clock64();
+#define PMARK(i) do { const unsigned long long n_ = wall_clock64(); pt[i] += n_ - pl; pl = n_; } while (0)
+#else
+#define PMARK(i) do { } while (0)
+#endif
     for (int it = 0; row < rows; ++it) {
+        PMARK(0);
         const int slot = it & 1;                                    // slot of `row`: free once everyone holds `row` and `next`
         C u[16], v[16];
         if constexpr (!INV) {
@@ -286,30 +346,39 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : 1)) void fused_l2_kernel
                 lds_barrier();
 #pragma unroll
                 for (int m = 0; m < 16; ++m) { const R a = rd[m], b = rd[m + 16]; v[m].y = hi ? a - b : a + b; }
+                if (hi) {                                           // (a branch, not a select: the 30 constants stay out of the registers)
 #pragma unroll
-                for (int m = 1; m < 16; ++m) {
-                    const C w = C{hi ? (R) root64_re(2 * m) : (R) 1, hi ? (R) root64_im(2 * m) : (R) 0};      // W_32^{s'}
-                    v[m] = cmul(v[m], w);
+                    for (int m = 1; m < 16; ++m) v[m] = cmul(v[m], C{(R) root64_re(2 * m), (R) root64_im(2 * m)});      // W_32^{s'}
                 }
             }
             dft16<R, false>(v);                                     // over s (s') -> k in v[brev(k)]: k2 = tau + TPL k
-            four_step_twiddle16<R, false, true, TPL>(v, twL, j1r, rtau);
-            if (it > 0) {                                           // the team has finished READING the previous row's A
-                spin(-1);
-                join();
+            four_step_twiddle16<R, false, true, TPL>(v, twL, opaque_j1(), rtau);
+            PMARK(1);
+            // A may be written again once it has been read: by this team (its previous row) and, in a pair, by the partner (whose
+            // turn lay in between — unless it has run out of rows, which is why the team's own count is checked as well)
+            if (it > 0) {
+                wait_read(tb + 8, (unsigned) kTS * (unsigned) it);
                 if (broken) return;
             }
+            if (has_partner) {
+                const unsigned need = (unsigned) kTS * (unsigned) ((team & 1) ? it + 1 : it);
+                if (need > 0) { wait_read(pb + 8, need); if (broken) return; }
+            }
+            PMARK(2);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) buf_store<kCached>(v[brev(k, 4)], rwork, aoff, k * ASTEP);
+            for (int k = 0; k < 16; ++k) st<kCached>(v[brev(k, 4)], rwork, aoff, k * ASTEP);
             arrive(true, slot);
+            PMARK(3);
             spin(slot);
             join();
+            PMARK(4);
             if (broken) return;
             // ================= column task: A -> bins
             const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *) (bins_out + (size_t) row * bins_pitch), 0, bins_len * CB, 0x00020000);
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = buf_load<kCoherent>(rwork, woff, i * WSTEP, R{});
             release_scratch();
+            PMARK(5);
             dft16<R, false>(v);                                     // over i -> k1' in v[brev(k1')]
 #pragma unroll
             for (int k = 1; k < 16; ++k) v[brev(k, 4)] = cmul(v[brev(k, 4)], wtab[W1 * t * k]);
@@ -329,10 +398,11 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : 1)) void fused_l2_kernel
                 for (int tp = 0; tp < 16; ++tp) u[tp].y = xr[tp * NC];
                 lds_barrier();
             }
+            if constexpr (PAIRED) { if (next < rows) request(cur, cur_last, next); }    // v is dead: its registers take the next row
             dft16<R, false>(u);                                     // over t' -> k: u[p] = Z[k1 = t + 16 brev(p)][col]
             if constexpr (!REAL) {
 #pragma unroll
-                for (int p = 0; p < 16; ++p) buf_store<kStream>(u[p], rb, boff, 16 * brev(p, 4) * BSTEP);
+                for (int p = 0; p < 16; ++p) st<kStream>(u[p], rb, boff, 16 * brev(p, 4) * BSTEP);
             } else {
                 // packed-real pass: a = Z[k1][col] (own), b = Z[255 - k1][256 - col] (256 - k1 in column 0), through the plane
                 R bx[16];
@@ -345,7 +415,7 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : 1)) void fused_l2_kernel
 #pragma unroll
                 for (int p = 0; p < 16; ++p) mine[brev(p, 4) * 16 * NC] = u[p].y;
                 lds_barrier();
-                C wt = wt0;
+                C wt = wt0, xlast = C{(R) 0, (R) 0};
                 asm volatile("" : "+v"(wt.x), "+v"(wt.y));
 #pragma unroll
                 for (int p = 0; p < 16; ++p) {
@@ -358,10 +428,15 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : 1)) void fused_l2_kernel
                     C xk = C{(R) 0.5 * sx + (dx * wqx - dy * wqy), (R) 0.5 * sy + (dx * wqy + dy * wqx)};
                     if (p == 0 && col0 && t == 0) {                 // k = 0: X[0], X[L] real (dsc_fft.h:221-225)
                         xk = C{ax + ay, (R) 0};
-                        buf_store<BS>(C{ax - ay, (R) 0}, rb, L * CB, 0);
+                        xlast = C{ax - ay, (R) 0};
                     }
-                    buf_store<BS>(xk, rb, boff, 16 * k3 * BSTEP);
+                    u[p] = xk;
                 }
+                __builtin_amdgcn_sched_barrier(0);                  // all values final before the first store (see the inverse row task)
+                if (col0 && t == 0) st<BS>(xlast, rb, L * CB, 0);
+#pragma unroll
+                for (int p = 0; p < 16; ++p) st<BS>(u[p], rb, boff, 16 * brev(p, 4) * BSTEP);
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
             // ================= column task backwards: bins -> A (scratch)
@@ -411,13 +486,18 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : 1)) void fused_l2_kernel
                 for (int k = 0; k < 16; ++k) u[k].y = xr[k * 16 * NC];
             }
             dft16<R, true>(u);                                      // over k1' -> i in u[brev(i)]: A[t + 16 i][col]
+            // A may be written again once it has been read: by this team (its previous row) and, in a pair, by the partner (whose
+            // turn lay in between — unless it has run out of rows, which is why the team's own count is checked as well)
             if (it > 0) {
-                spin(-1);
-                join();
+                wait_read(tb + 8, (unsigned) kTS * (unsigned) it);
                 if (broken) return;
             }
+            if (has_partner) {
+                const unsigned need = (unsigned) kTS * (unsigned) ((team & 1) ? it + 1 : it);
+                if (need > 0) { wait_read(pb + 8, need); if (broken) return; }
+            }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) buf_store<kCached>(u[brev(i, 4)], rwork, woff, i * WSTEP);
+            for (int i = 0; i < 16; ++i) st<kCached>(u[brev(i, 4)], rwork, woff, i * WSTEP);
             arrive(true, slot);
             spin(slot);
             join();
@@ -427,7 +507,7 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : 1)) void fused_l2_kernel
 #pragma unroll
             for (int k = 0; k < 16; ++k) v[k] = buf_load<kCoherent>(rwork, aoff, k * ASTEP, R{});
             release_scratch();
-            four_step_twiddle16<R, true, false, TPL>(v, twL, j1r, rtau);
+            four_step_twiddle16<R, true, false, TPL>(v, twL, opaque_j1(), rtau);
             dft16<R, true>(v);                                      // over k -> s (s') in v[brev(.)]
             if constexpr (L2 == 256) {
 #pragma unroll
@@ -448,10 +528,9 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : 1)) void fused_l2_kernel
             } else {
                 // x[s'] = y_0[s'] + conj(W_32^{s'}) y_1[s'], x[s' + 16] = y_0[s'] - ...: this lane holds y_c, the +- is taken by the reader
                 const bool hi = rtau >= 16;
+                if (hi) {
 #pragma unroll
-                for (int m = 1; m < 16; ++m) {
-                    const C w = C{hi ? (R) root64_re(2 * m) : (R) 1, hi ? (R) root64_im(2 * m) : (R) 0};
-                    v[brev(m, 4)] = cmulc(v[brev(m, 4)], w);
+                    for (int m = 1; m < 16; ++m) v[brev(m, 4)] = cmulc(v[brev(m, 4)], C{(R) root64_re(2 * m), (R) root64_im(2 * m)});
                 }
                 R *wr = plane + rq * kPQ5 + (rtau & 15) * kPK5 + (hi ? 16 : 0);      // plane[q][ka][s' + 16 c]
                 const R *rd = plane + wq * kPQ5 + (ws & 15);
@@ -471,25 +550,33 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : 1)) void fused_l2_kernel
                 for (int k = 1; k < 16; ++k) u[k] = cmulc(u[k], wtab[ws * k]);       // conj W_512^{s ka}
             }
             dft16<R, true>(u);                                      // over tau -> m in u[brev(m)]
+            // (all 16 values are final before the first store: no store's data registers are rewritten while it drains)
 #pragma unroll
-            for (int m = 0; m < 16; ++m) {
-                const C r = u[brev(m, 4)];
-                buf_store<kStream>(C{r.x * scale, r.y * scale}, ro, zoff, m * ZSTEP);
-            }
+            for (int m = 0; m < 16; ++m) u[m] = C{u[m].x * scale, u[m].y * scale};
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 16; ++m) st<kStream>(u[brev(m, 4)], ro, zoff, m * ZSTEP);
+            __builtin_amdgcn_sched_barrier(0);
+            // PAIRED: the inverse has no registers to spare in its second task (requesting earlier spills 50 of them and costs 30 %)
+            if constexpr (PAIRED) { if (next < rows) request(cur, cur_last, next); }
         }
+        PMARK(6);
         // the row after next was published in `slot` at the first barrier of this row
         const int after = __builtin_amdgcn_readfirstlane(info[4 + slot]);
         row = next; next = after;
-#pragma unroll
-        for (int m = 0; m < 16; ++m) cur[m] = nxt[m];
-        cur_last = nxt_last;
     }
+    leave();
+#ifdef DSC_FUSED_PROFILE
+    if (tid == 0 && xcc == 0 && team == 0 && (rank == 0 || rank == 7))
+        printf("fused_l2 profile rank %d (10 ns ticks, sums over the rows of this team): loop %llu | phase-1 compute %llu | wait B %llu | store A + arrive %llu | wait A %llu | read A + request %llu | phase 2 %llu\n",
+               rank, pt[0], pt[1], pt[2], pt[3], pt[4], pt[5], pt[6]);
+#endif
 }
 
 // workgroups per CU the launch asks for, and the rows of scratch that implies (one per possible team, + 1 per XCD of slack for an
 // uneven dispatch).  f32 rows of 512 KiB: six teams per XCD (3 MiB of its 4 MiB L2); f64 1 MiB: two; 2 MiB (L2 = 512, f64): one.
-constexpr int wg_per_cu(bool single_precision) { return single_precision ? 3 : 1; }
-constexpr int teams_cap_of(int L, bool single_precision) { return wg_per_cu(single_precision) * 32 / (L / 256 / 16) + 1; }
+constexpr int wg_per_cu(int L, bool single_precision) { return single_precision ? 3 : L == 131072 ? 2 : 1; }
+constexpr int teams_cap_of(int L, bool single_precision) { return wg_per_cu(L, single_precision) * 32 / (L / 256 / 16) + 1; }
 
 template<typename R, bool REAL, bool INV, int L2>
 bool launch_one(const void *in, void *out, long long rows, void *scratch, unsigned *host_error, const void *tw_full, const void *tw_real, double scale,
@@ -505,7 +592,7 @@ bool launch_one(const void *in, void *out, long long rows, void *scratch, unsign
         int per_cu = 0, cus = 0;
         DSC_KERNEL_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *) fused_l2_kernel<R, REAL, INV, L2>, kNT, 0));
         DSC_KERNEL_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        if (per_cu > wg_per_cu(sizeof(R) == 4)) per_cu = wg_per_cu(sizeof(R) == 4);
+        if (per_cu > wg_per_cu(L, sizeof(R) == 4)) per_cu = wg_per_cu(L, sizeof(R) == 4);
         int g = cus * per_cu;
         g -= g % (8 * TS);
         if (g > 8 * TS * (cap - 1)) g = 8 * TS * (cap - 1);
@@ -528,11 +615,10 @@ size_t dsc_fft_fused_l2_ctl_bytes() { return (sizeof(fused_ctl) + 4095) / 4096 *
 // complex length 65536 (256 x 256), f32 and f64; 131072 (256 x 512) in f64 = BASELINE config 5 (its 512-point row tasks read
 // 8 adjacent lines: 128-B pieces in f64, only 64 B in f32 — measured 2.21 / 2.00 / 2.02 ms for rfft / irfft / fft against 1.94 /
 // 1.78 / 1.51 ms on the two-kernel route, so f32 stays there)
-// The inverse REAL transform of 131072 bins is the one case measured slower than the two-kernel route (4.16 vs 3.82 ms: one team
-// per XCD, nothing overlaps its longer first phase) and stays there.
 bool dsc_fft_fused_l2_supports(int L, bool single_precision, bool real, bool inverse) {
     if (L == 65536) return true;
-    return L == 131072 && !single_precision && !(real && inverse);
+    (void) real; (void) inverse;
+    return L == 131072 && !single_precision;
 }
 
 // bytes of scratch a launch needs: the control block + one row of A per possible team

@@ -194,7 +194,7 @@ def test_f64_262144_register_path(dsc):
     for rows in (1, 3, 37):
         x = rng.standard_normal((rows, 262144))
         X = dsc.rfft(dsc.from_numpy(x))
-        assert dsc.last_fft_path() == 'r2c_fused_l2'       # round 2: one launch, intermediate in the XCD-local L2 (the inverse keeps two kernels)
+        assert dsc.last_fft_path() == 'r2c_fused_l2'       # round 2: one launch, intermediate in the XCD-local L2
         got = X.numpy()
         for r in sorted({0, rows - 1}):
             assert_close(got[r], port.rfft(x[r]), what=f'f64 rfft row {r}/{rows}')
@@ -203,7 +203,7 @@ def test_f64_262144_register_path(dsc):
         Xq = got.copy()
         Xq[:, 0] += 2j                                     # imaginary parts of bins 0 and n are ignored (dsc_fft.h:227-228)
         back = dsc.irfft(dsc.from_numpy(Xq))
-        assert dsc.last_fft_path() == 'c2r_2pass_regs'
+        assert dsc.last_fft_path() == 'c2r_fused_l2'
         bh = back.numpy()
         assert_close(bh[0], port.irfft(Xq[0]), what='f64 irfft')
         assert rel_l2(bh, x) <= 1e-14
@@ -350,7 +350,7 @@ def test_full_size_f64_config5(dsc):
     assert rel_l2(Xh, Xh[idx] * (scale / scale[idx])[:, None]) <= 1e-15
     del p, tx                                          # three 4 GiB tensors do not fit the 12 GiB test arena next to cached plans
     back = dsc.irfft(X)
-    assert dsc.last_fft_path() == 'c2r_2pass_regs'
+    assert dsc.last_fft_path() == 'c2r_fused_l2'
     bh = back.numpy()
     assert rel_l2(bh, x) <= 1e-14 and np.max(np.abs(bh - x)) < 1e-12
 
@@ -492,6 +492,29 @@ def test_fused_l2_team_kernel_many_rows(dsc):
     dsc.synchronize()
 
 
+def test_fused_l2_paired_teams_every_element(dsc):
+    """Config-5 shape on the team kernel (f64, 131072-point rows: two teams per XCD take turns on ONE scratch row): repeated
+    launches, every element of every row against numpy — a wrong store shows up as 16 elements of one row (tools/stress_fused.py
+    found two such bugs: a team overwriting its own intermediate after its partner had left, and 128-bit store data rewritten by
+    the next multiply).  3 rows: teams with and without work; 40: several rows per team."""
+    rng = np.random.default_rng(262)
+    for rows in (3, 40):
+        z = rng.standard_normal((rows, 131072)) + 1j * rng.standard_normal((rows, 131072))
+        x = rng.standard_normal((rows, 262144))
+        wf, wi, wr = np.fft.fft(z, axis=-1), np.fft.ifft(z, axis=-1), np.fft.rfft(x, axis=-1)
+        tz, tx = dsc.from_numpy(z), dsc.from_numpy(x)
+        for rep in range(4):
+            tX = dsc.from_numpy(wr)
+            for name, f, want, path in (('fft', lambda: dsc.fft(tz), wf, 'c2c_fused_l2'), ('ifft', lambda: dsc.ifft(tz), wi, 'c2c_fused_l2'),
+                                        ('rfft', lambda: dsc.rfft(tx), wr, 'r2c_fused_l2'), ('irfft', lambda: dsc.irfft(tX), x, 'c2r_fused_l2')):
+                got = f().numpy()
+                assert dsc.last_fft_path() == path
+                scale = np.max(np.abs(want), axis=1, keepdims=True)
+                worst = np.max(np.abs(got - want) / scale)
+                assert worst <= 1e-12, (name, rows, rep, worst)
+    dsc.synchronize()
+
+
 @pytest.mark.parametrize('dt,n', [(np.float32, 131072), (np.float64, 65536), (np.float64, 262144)])
 def test_two_pass_padded_rows(dsc, dt, n):
     """Zero padded / cropped rows on the two-pass kernels (the row descriptors end at the last valid sample / bin)."""
@@ -507,7 +530,7 @@ def test_two_pass_padded_rows(dsc, dt, n):
     for rows, lb in ((2, bins - 5), (3, bins + 9)):
         Y = (rng.standard_normal((rows, lb)) + 1j * rng.standard_normal((rows, lb))).astype(cdt)
         b = dsc.irfft(dsc.from_numpy(Y), n=bins)
-        assert dsc.last_fft_path() == ('c2r_fused_l2' if dt == np.float32 else 'c2r_2pass_regs')
+        assert dsc.last_fft_path() == ('c2r_fused_l2' if n in (131072, 262144) else 'c2r_2pass_regs')
         assert_close(b.numpy()[0], port.irfft(Y[0], bins), what=f'padded 2-pass irfft bins={bins} lb={lb}')
 
 
