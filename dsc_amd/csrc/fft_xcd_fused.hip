@@ -117,7 +117,7 @@ __device__ __forceinline__ void four_step_twiddle16(cpx<R> (&v)[16], const cpx<R
 // bins = the frequency-domain side: row pitch bins_pitch bins, bins_len valid bins
 // L2 = 256 or 512: the row-task transform length (L = 256 L2); TS = L2 / 16 workgroups per team.
 template<typename R, bool REAL, bool INV, int L2>
-__global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : L2 == 512 ? 2 : 1)) void fused_l2_kernel(const char *__restrict__ ext, char *__restrict__ ext_out,
+__global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : 2)) void fused_l2_kernel(const char *__restrict__ ext, char *__restrict__ ext_out,
                                                                                const cpx<R> *__restrict__ bins_in, cpx<R> *__restrict__ bins_out,
                                                                                cpx<R> *scratch, fused_ctl *ctl, unsigned *host_error, int rows, int teams_cap,
                                                                                const cpx<R> *__restrict__ twL, const cpx<R> *__restrict__ tw_real, R scale,
@@ -159,10 +159,13 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : L2 == 512 ? 2 : 1)) void
     if (team >= __builtin_amdgcn_readfirstlane(info[3]) || team >= kMaxTeams || team >= teams_cap) return;               // workgroups that do not fill a team
     // Counters of a team (one 256-B block in the XCD's L2): [0] arrivals at "A is written", [4] / [5] published rows, [8] arrivals
     // at "A has been read", [12] members that have left.
-    // PAIRED (2 MiB of A per row: the L2 has room for ONE): teams 2p and 2p + 1 of an XCD share one scratch row and take turns —
-    // a team may write A only once its partner has read its own; while one team is in its write -> barrier -> read window the
-    // other computes its column task and the next row task.  Two workgroups per CU, one row of A live per XCD.
-    constexpr bool PAIRED = L2 == 512;
+    // PAIRED (f64: 1 or 2 MiB of A per row, and the 4 MiB L2 also carries the streams): teams 2p and 2p + 1 of an XCD share one
+    // scratch row and take turns — a team may write A only once its partner has read its own; while one team is in its
+    // write -> barrier -> read window the other computes its column task and the next row task.  Two workgroups per CU; per XCD
+    // one row of A is live at L = 131072 (one pair), two at L = 65536 (two pairs).  Measured against unpaired teams with a row
+    // each: c64 L = 65536 1.31 -> 1.07 ms, rfft f64 N = 131072 1.52 -> 1.20 ms, config 5 3.37 -> 3.0-3.2 ms; in f32 (six teams of
+    // 16 per XCD already overlap) pairing is a wash (rfft +5 %, fft -12 %) and is not used.
+    constexpr bool PAIRED = sizeof(R) == 8;
     unsigned *tb = &ctl->team[xcc * kMaxTeams + team][0];
     const int n_teams = __builtin_amdgcn_readfirstlane(info[3]) < teams_cap ? __builtin_amdgcn_readfirstlane(info[3]) : teams_cap;
     const bool has_partner = PAIRED && (team ^ 1) < n_teams && (team ^ 1) < kMaxTeams;
@@ -574,8 +577,9 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : L2 == 512 ? 2 : 1)) void
 }
 
 // workgroups per CU the launch asks for, and the rows of scratch that implies (one per possible team, + 1 per XCD of slack for an
-// uneven dispatch).  f32 rows of 512 KiB: six teams per XCD (3 MiB of its 4 MiB L2); f64 1 MiB: two; 2 MiB (L2 = 512, f64): one.
-constexpr int wg_per_cu(int L, bool single_precision) { return single_precision ? 3 : L == 131072 ? 2 : 1; }
+// uneven dispatch).  f32 rows of 512 KiB: six teams per XCD (3 MiB of its 4 MiB L2); f64: two workgroups per CU, teams in pairs
+// that share a row (1 MiB rows: four teams, 2 MiB: two).
+constexpr int wg_per_cu(int L, bool single_precision) { (void) L; return single_precision ? 3 : 2; }
 constexpr int teams_cap_of(int L, bool single_precision) { return wg_per_cu(L, single_precision) * 32 / (L / 256 / 16) + 1; }
 
 template<typename R, bool REAL, bool INV, int L2>

@@ -493,14 +493,15 @@ def test_fused_l2_team_kernel_many_rows(dsc):
 
 
 def test_fused_l2_paired_teams_every_element(dsc):
-    """Config-5 shape on the team kernel (f64, 131072-point rows: two teams per XCD take turns on ONE scratch row): repeated
+    """The paired teams of the team kernel (f64: config 5's 131072-point rows — two teams per XCD take turns on ONE scratch row —
+    and 65536-point rows, two pairs per XCD): repeated
     launches, every element of every row against numpy — a wrong store shows up as 16 elements of one row (tools/stress_fused.py
     found two such bugs: a team overwriting its own intermediate after its partner had left, and 128-bit store data rewritten by
     the next multiply).  3 rows: teams with and without work; 40: several rows per team."""
     rng = np.random.default_rng(262)
-    for rows in (3, 40):
-        z = rng.standard_normal((rows, 131072)) + 1j * rng.standard_normal((rows, 131072))
-        x = rng.standard_normal((rows, 262144))
+    for rows, L in ((3, 131072), (40, 131072), (70, 65536)):
+        z = rng.standard_normal((rows, L)) + 1j * rng.standard_normal((rows, L))
+        x = rng.standard_normal((rows, 2 * L))
         wf, wi, wr = np.fft.fft(z, axis=-1), np.fft.ifft(z, axis=-1), np.fft.rfft(x, axis=-1)
         tz, tx = dsc.from_numpy(z), dsc.from_numpy(x)
         for rep in range(4):
