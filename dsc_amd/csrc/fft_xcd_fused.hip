@@ -31,6 +31,11 @@ namespace {
 constexpr int kNT = 256;                  // threads per workgroup
 constexpr int kMaxTeams = 8;              // teams per XCD
 constexpr int kPQ = 276, kPK = 17;        // row-task exchange: line pitch (values), k2' pitch
+// (experiment: pairs for f32 as well, at four workgroups per CU — 128 VGPRs fit — measured rfft 1.44-1.47 vs 1.47-1.49 ms, fft 1.28 vs
+// 1.14-1.17 ms: not adopted)
+#ifndef DSC_FUSED_F32_PAIRED
+#define DSC_FUSED_F32_PAIRED 0
+#endif
 #ifndef DSC_FUSED_BINS_LOAD
 #define DSC_FUSED_BINS_LOAD kCached
 #endif
@@ -117,7 +122,7 @@ __device__ __forceinline__ void four_step_twiddle16(cpx<R> (&v)[16], const cpx<R
 // bins = the frequency-domain side: row pitch bins_pitch bins, bins_len valid bins
 // L2 = 256 or 512: the row-task transform length (L = 256 L2); TS = L2 / 16 workgroups per team.
 template<typename R, bool REAL, bool INV, int L2>
-__global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : 2)) void fused_l2_kernel(const char *__restrict__ ext, char *__restrict__ ext_out,
+__global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? (DSC_FUSED_F32_PAIRED ? 4 : 3) : 2)) void fused_l2_kernel(const char *__restrict__ ext, char *__restrict__ ext_out,
                                                                                const cpx<R> *__restrict__ bins_in, cpx<R> *__restrict__ bins_out,
                                                                                cpx<R> *scratch, fused_ctl *ctl, unsigned *host_error, int rows, int teams_cap,
                                                                                const cpx<R> *__restrict__ twL, const cpx<R> *__restrict__ tw_real, R scale,
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : 2)) void fused_l2_kernel
     // one row of A is live at L = 131072 (one pair), two at L = 65536 (two pairs).  Measured against unpaired teams with a row
     // each: c64 L = 65536 1.31 -> 1.07 ms, rfft f64 N = 131072 1.52 -> 1.20 ms, config 5 3.37 -> 3.0-3.2 ms; in f32 (six teams of
     // 16 per XCD already overlap) pairing is a wash (rfft +5 %, fft -12 %) and is not used.
-    constexpr bool PAIRED = sizeof(R) == 8;
+    constexpr bool PAIRED = sizeof(R) == 8 || DSC_FUSED_F32_PAIRED;
     unsigned *tb = &ctl->team[xcc * kMaxTeams + team][0];
     const int n_teams = __builtin_amdgcn_readfirstlane(info[3]) < teams_cap ? __builtin_amdgcn_readfirstlane(info[3]) : teams_cap;
     const bool has_partner = PAIRED && (team ^ 1) < n_teams && (team ^ 1) < kMaxTeams;
@@ -579,7 +584,7 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? 3 : 2)) void fused_l2_kernel
 // workgroups per CU the launch asks for, and the rows of scratch that implies (one per possible team, + 1 per XCD of slack for an
 // uneven dispatch).  f32 rows of 512 KiB: six teams per XCD (3 MiB of its 4 MiB L2); f64: two workgroups per CU, teams in pairs
 // that share a row (1 MiB rows: four teams, 2 MiB: two).
-constexpr int wg_per_cu(int L, bool single_precision) { (void) L; return single_precision ? 3 : 2; }
+constexpr int wg_per_cu(int L, bool single_precision) { (void) L; return single_precision ? (DSC_FUSED_F32_PAIRED ? 4 : 3) : 2; }
 constexpr int teams_cap_of(int L, bool single_precision) { return wg_per_cu(L, single_precision) * 32 / (L / 256 / 16) + 1; }
 
 template<typename R, bool REAL, bool INV, int L2>
