@@ -182,3 +182,29 @@ print('OK', path, err)
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'OK' in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
     assert 'generic' in r.stdout, r.stdout             # no room for the transposes: the strided LDS kernel took it
+
+
+def test_fused_l2_falls_back_when_scratch_is_small_or_switched_off():
+    """fft_xcd_fused.hip needs one scratch row per possible team (29 MiB for f32 rows of 512 KiB): a context with less scratch, or
+    DSC_NO_FUSED_L2 in the environment, takes the two-kernel route — same results.  Own processes: arena sizes and the switch are
+    fixed at start."""
+    code = r'''
+import sys, os
+sys.path.insert(0, %r)
+import numpy as np
+import dsc_amd as dsc
+dsc.init(1 << 30, int(sys.argv[1]) << 20)
+x = np.random.default_rng(4).standard_normal((9, 131072)).astype(np.float32)
+X = dsc.rfft(dsc.from_numpy(x))
+path = dsc.last_fft_path()
+want = np.fft.rfft(x.astype(np.float64), axis=-1)
+err = np.linalg.norm(X.numpy() - want) / np.linalg.norm(want)
+back = dsc.irfft(X).numpy()
+assert err <= 1e-6 and np.max(np.abs(back - x)) < 1e-4, err
+dsc.synchronize()
+print('OK', path, dsc.last_fft_path())
+''' % ROOT
+    for scratch_mb, env, want in ((256, {}, 'r2c_fused_l2 c2r_fused_l2'), (12, {}, 'r2c_2pass_regs c2r_2pass_regs'),
+                                  (256, {'DSC_NO_FUSED_L2': '1'}, 'r2c_2pass_regs c2r_2pass_regs')):
+        r = subprocess.run([sys.executable, '-c', code, str(scratch_mb)], capture_output=True, text=True, timeout=600, env={**os.environ, **env})
+        assert r.returncode == 0 and ('OK ' + want) in r.stdout, (scratch_mb, env, r.stdout[-300:], r.stderr[-800:])
