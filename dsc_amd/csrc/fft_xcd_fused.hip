@@ -145,7 +145,7 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? (DSC_FUSED_F32_PAIRED ? 4 : 
 
     // ---- teams
     if (tid == 0) {
-        const unsigned x = xcc_id();
+        const unsigned x = xcc_id() & 7u;                           // MI355X: 8 XCDs (the control block has 8 slots)
         const unsigned arr = l2_fetch_add(&ctl->xcc_count[x][0], 1u);
         info[0] = (int) x; info[1] = (int) arr; info[2] = 0;
         atomicAdd(&ctl->arrived, 1u);
