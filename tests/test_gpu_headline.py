@@ -492,6 +492,35 @@ def test_fused_l2_team_kernel_many_rows(dsc):
     dsc.synchronize()
 
 
+def test_every_element_of_the_f64_paths_with_128_bit_stores(dsc):
+    """Every element of every row, repeatedly (an L2-norm check does not see a handful of wrong elements in one row): the f64
+    kernels that store c64 values 16 bytes per lane at two waves per SIMD — the mid-size register kernel, the two-pass kernels, the
+    column kernel.  tools/stress_64k.py is the long form (it also covers the 65536-point f32 kernels)."""
+    rng = np.random.default_rng(64)
+
+    def worst(got, want):
+        return float(np.max(np.abs(got - want) / np.max(np.abs(want), axis=1, keepdims=True)))
+
+    for n, rows in ((4096, 2048), (65536, 128)):
+        xd = rng.standard_normal((rows, n))
+        wd = np.fft.rfft(xd, axis=-1)
+        zd = rng.standard_normal((rows, n // 2)) + 1j * rng.standard_normal((rows, n // 2))
+        wz = np.fft.fft(zd, axis=-1)
+        td, tD, tz = dsc.from_numpy(xd), dsc.from_numpy(wd), dsc.from_numpy(zd)
+        for rep in range(3):
+            assert worst(dsc.rfft(td).numpy(), wd) <= 1e-12, (n, rep, 'rfft', dsc.last_fft_path())
+            assert worst(dsc.irfft(tD).numpy(), xd) <= 1e-12, (n, rep, 'irfft', dsc.last_fft_path())
+            assert worst(dsc.fft(tz).numpy(), wz) <= 1e-12, (n, rep, 'fft', dsc.last_fft_path())
+        del td, tD, tz
+    xd = rng.standard_normal((1024, 2048))
+    zd = xd + 1j * rng.standard_normal((1024, 2048))
+    td, tz = dsc.from_numpy(xd), dsc.from_numpy(zd)
+    wd, wz = np.fft.rfft(xd, axis=0), np.fft.fft(zd, axis=0)
+    for rep in range(3):
+        assert worst(dsc.rfft(td, axis=0).numpy().T, wd.T) <= 1e-12 and dsc.last_fft_path() == 'regs_cols'
+        assert worst(dsc.fft(tz, axis=0).numpy().T, wz.T) <= 1e-12
+
+
 def test_fused_l2_paired_teams_every_element(dsc):
     """The paired teams of the team kernel (f64: config 5's 131072-point rows — two teams per XCD take turns on ONE scratch row —
     and 65536-point rows, two pairs per XCD): repeated
