@@ -1,5 +1,6 @@
-// fft_xcd_fused.hip — 65536-point complex rows (real length 131072) in ONE launch, the four-step intermediate held in the L2
-// of the XCD that works on the row instead of making a round trip through HBM (fft_r2c_2pass.hip moves every row twice).
+// fft_xcd_fused.hip — long complex rows (L = 256 x L2: 32768 and 131072 points in f64, 65536 in f32 and f64; real lengths twice
+// that) in ONE launch, the four-step intermediate held in the L2 of the XCD that works on the row instead of making a round trip
+// through HBM (fft_r2c_2pass.hip moves every row twice).  Described for L2 = 256:
 //
 //   j = j1 + 256 j2   (input),      k = 256 k1 + k2   (output),      j1, k1, j2, k2 < 256
 //   rows  A[j1][k2] = W_L^{j1 k2} * sum_{j2} z[j1 + 256 j2] W_256^{j2 k2}       256-point FFTs, tasks of 16 adjacent j1
@@ -98,7 +99,15 @@ __device__ __forceinline__ void dft16(cpx<R> (&v)[16]) {
     x_stage<R, INV, 2>(v, std::make_integer_sequence<int, 8>{});
 }
 
-// W_L^{j1 (tau + S k)}, k = 4 a + b: W_L^{j1 tau} W_L^{4 S j1 a} W_L^{S j1 b}, three exact table values (S = 16 or 32)
+// two 8-point DFTs, of v[0..7] and of v[8..15]: natural order in, v[8 h + p] = bin brev(p, 3) of half h
+template<typename R, bool INV>
+__device__ __forceinline__ void dft8x2(cpx<R> (&v)[16]) {
+    x_stage<R, INV, 8>(v, std::make_integer_sequence<int, 2>{});
+    x_stage<R, INV, 4>(v, std::make_integer_sequence<int, 4>{});
+    x_stage<R, INV, 2>(v, std::make_integer_sequence<int, 8>{});
+}
+
+// W_L^{j1 (tau + S k)}, k = 4 a + b: W_L^{j1 tau} W_L^{4 S j1 a} W_L^{S j1 b}, three exact table values (S = 8, 16 or 32)
 template<typename R, bool CONJ, bool BREV, int S>
 __device__ __forceinline__ void four_step_twiddle16(cpx<R> (&v)[16], const cpx<R> *twL, int j1, int tau) {
     using C = cpx<R>;
@@ -136,12 +145,14 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? (DSC_FUSED_F32_PAIRED ? 4 : 
     // ... and written in 64-B pieces that straddle sectors: with the default policy the pieces of the 16 column tasks of a row
     // (same XCD, same moment) meet in the L2 and leave as whole lines
     constexpr int BS = REAL ? DSC_FUSED_BINS_STORE : kStream;
-    __shared__ __attribute__((aligned(16))) R plane[16 * kPQ];      // row task: 16 lines x kPQ; column task: [k1][ell] 257 x 16
-    __shared__ C wtab[L2];                                          // W_L2^m
+    constexpr int kPQ1 = 148, kPK1 = 9;                             // ... of the 128-point lines (32 lines)
+    __shared__ __attribute__((aligned(16))) R plane[L2 == 128 ? 32 * kPQ1 : 16 * kPQ];      // row task: LINES x pitch; column task: [k1][ell] 257 x 16
+    constexpr int TAB = L2 > 256 ? L2 : 256;                        // W_TAB^m: W_256^m = wtab[W1 m], W_L2^m = wtab[W2 m]
+    __shared__ C wtab[TAB];
     __shared__ int info[8];
     const int tid = threadIdx.x;
-    for (int i = tid; i < L2; i += kNT) wtab[i] = twL[i * 256];
-    constexpr int W1 = L2 / 256;                                    // W_256^m = wtab[W1 m]
+    for (int i = tid; i < TAB; i += kNT) wtab[i] = twL[i * (L / TAB)];
+    constexpr int W1 = TAB / 256, W2 = TAB / L2;
 
     // ---- teams
     if (tid == 0) {
@@ -322,7 +333,7 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? (DSC_FUSED_F32_PAIRED ? 4 : 
             // ================= row task: samples -> A (scratch)
             dft16<R, false>(cur);                                   // over m -> first index in cur[brev(.)]
 #pragma unroll
-            for (int k = 1; k < 16; ++k) cur[brev(k, 4)] = cmul(cur[brev(k, 4)], wtab[ws * k]);
+            for (int k = 1; k < 16; ++k) cur[brev(k, 4)] = cmul(cur[brev(k, 4)], wtab[W2 * ws * k]);
             if constexpr (L2 == 256) {
                 R *wr = plane + wq * kPQ + ws;
                 const R *rd = plane + rq * kPQ + rtau * kPK;
@@ -337,6 +348,22 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? (DSC_FUSED_F32_PAIRED ? 4 : 
                 lds_barrier();
 #pragma unroll
                 for (int m = 0; m < 16; ++m) v[m].y = rd[m];
+            } else if constexpr (L2 == 128) {
+                // 8-point second stage: lane tau takes the two first-stage bins ka = tau and tau + 8 (so that it ends up with
+                // k2 = tau + 8 k, 8 adjacent lanes = 128 contiguous bytes of A)
+                R *wr = plane + wq * kPQ1 + ws;                     // plane[q][ka][s], s < 8
+                const R *rd = plane + rq * kPQ1 + rtau * kPK1;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) wr[k * kPK1] = cur[brev(k, 4)].x;
+                lds_barrier();
+#pragma unroll
+                for (int m = 0; m < 8; ++m) { v[m].x = rd[m]; v[8 + m].x = rd[8 * kPK1 + m]; }
+                lds_barrier();
+#pragma unroll
+                for (int k = 0; k < 16; ++k) wr[k * kPK1] = cur[brev(k, 4)].y;
+                lds_barrier();
+#pragma unroll
+                for (int m = 0; m < 8; ++m) { v[m].y = rd[m]; v[8 + m].y = rd[8 * kPK1 + m]; }
             } else {
                 // 32-point second stage over s = s' + 16 c: y_c[s'] = (x[s'] +- x[s' + 16]) (W_32^{s'} for c = 1), then 16 points
                 // over s': bin kr = 2 kb + c.  The +- is taken while reading the exchange plane.
@@ -359,8 +386,17 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? (DSC_FUSED_F32_PAIRED ? 4 : 
                     for (int m = 1; m < 16; ++m) v[m] = cmul(v[m], C{(R) root64_re(2 * m), (R) root64_im(2 * m)});      // W_32^{s'}
                 }
             }
-            dft16<R, false>(v);                                     // over s (s') -> k in v[brev(k)]: k2 = tau + TPL k
-            four_step_twiddle16<R, false, true, TPL>(v, twL, opaque_j1(), rtau);
+            if constexpr (L2 == 128) {
+                dft8x2<R, false>(v);                                // v[8 h + p]: ka = tau + 8 h, kr = brev(p, 3): k2 = ka + 16 kr = tau + 8 (2 kr + h)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) u[k] = v[8 * (k & 1) + brev(k >> 1, 3)];
+                four_step_twiddle16<R, false, false, TPL>(u, twL, opaque_j1(), rtau);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v[brev(k, 4)] = u[k];  // the order the stores below expect
+            } else {
+                dft16<R, false>(v);                                 // over s (s') -> k in v[brev(k)]: k2 = tau + TPL k
+                four_step_twiddle16<R, false, true, TPL>(v, twL, opaque_j1(), rtau);
+            }
             PMARK(1);
             // A may be written again once it has been read: by this team (its previous row) and, in a pair, by the partner (whose
             // turn lay in between — unless it has run out of rows, which is why the team's own count is checked as well)
@@ -516,10 +552,31 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? (DSC_FUSED_F32_PAIRED ? 4 : 
             for (int k = 0; k < 16; ++k) v[k] = buf_load<kCoherent>(rwork, aoff, k * ASTEP, R{});
             release_scratch();
             four_step_twiddle16<R, true, false, TPL>(v, twL, opaque_j1(), rtau);
+            if constexpr (L2 == 128) {
+                // k = 2 kr + h: two inverse 8-point DFTs over kr (ka = tau + 8 h), then back through the plane
+#pragma unroll
+                for (int k = 0; k < 16; ++k) u[8 * (k & 1) + (k >> 1)] = v[k];
+                dft8x2<R, true>(u);                                 // u[8 h + p] = value for s = brev(p, 3)
+                R *wr = plane + rq * kPQ1 + rtau * kPK1;            // plane[q][ka = tau + 8 h][s]
+                const R *rd = plane + wq * kPQ1 + ws;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) { wr[brev(p, 3)] = u[p].x; wr[8 * kPK1 + brev(p, 3)] = u[8 + p].x; }
+                lds_barrier();
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v[k].x = rd[k * kPK1];
+                lds_barrier();
+#pragma unroll
+                for (int p = 0; p < 8; ++p) { wr[brev(p, 3)] = u[p].y; wr[8 * kPK1 + brev(p, 3)] = u[8 + p].y; }
+                lds_barrier();
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v[k].y = rd[k * kPK1];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) u[k] = k == 0 ? v[0] : cmulc(v[k], wtab[W2 * ws * k]);      // conj W_128^{s ka}
+            } else {
             dft16<R, true>(v);                                      // over k -> s (s') in v[brev(.)]
             if constexpr (L2 == 256) {
 #pragma unroll
-                for (int s = 1; s < 16; ++s) v[brev(s, 4)] = cmulc(v[brev(s, 4)], wtab[s * rtau]);
+                for (int s = 1; s < 16; ++s) v[brev(s, 4)] = cmulc(v[brev(s, 4)], wtab[W2 * s * rtau]);
                 R *wr = plane + rq * kPQ + rtau * kPK;
                 const R *rd = plane + wq * kPQ + ws;
 #pragma unroll
@@ -555,7 +612,8 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? (DSC_FUSED_F32_PAIRED ? 4 : 
 #pragma unroll
                 for (int k = 0; k < 16; ++k) { const R p0 = rd[k * kPK5], p1 = rd[k * kPK5 + 16]; u[k].y = up ? p0 - p1 : p0 + p1; }
 #pragma unroll
-                for (int k = 1; k < 16; ++k) u[k] = cmulc(u[k], wtab[ws * k]);       // conj W_512^{s ka}
+                for (int k = 1; k < 16; ++k) u[k] = cmulc(u[k], wtab[W2 * ws * k]);  // conj W_512^{s ka}
+            }
             }
             dft16<R, true>(u);                                      // over tau -> m in u[brev(m)]
             // (all 16 values are final before the first store: no store's data registers are rewritten while it drains)
@@ -626,6 +684,7 @@ size_t dsc_fft_fused_l2_ctl_bytes() { return (sizeof(fused_ctl) + 4095) / 4096 *
 // 1.78 / 1.51 ms on the two-kernel route, so f32 stays there)
 bool dsc_fft_fused_l2_supports(int L, bool single_precision, bool real, bool inverse) {
     if (L == 65536) return true;
+    if (L == 32768) return !single_precision;          // f32 has its own one-pass kernels at this length
     (void) real; (void) inverse;
     return L == 131072 && !single_precision;
 }
@@ -657,6 +716,7 @@ bool dsc_launch_fft_fused_l2(const void *in, void *out, long long rows, int L, b
     if (rows <= 0) return true;
     if (!dsc_fft_fused_l2_supports(L, single_precision, real, inverse) || rows > 0x7fffff00) return false;
     if (L == 131072) return launch_any<double, 512>(in, out, rows, real, inverse, scratch, host_error, tw_full, tw_real, in_pitch, in_len, stream);
+    if (L == 32768) return launch_any<double, 128>(in, out, rows, real, inverse, scratch, host_error, tw_full, tw_real, in_pitch, in_len, stream);
     return single_precision ? launch_any<float, 256>(in, out, rows, real, inverse, scratch, host_error, tw_full, tw_real, in_pitch, in_len, stream)
                             : launch_any<double, 256>(in, out, rows, real, inverse, scratch, host_error, tw_full, tw_real, in_pitch, in_len, stream);
 }

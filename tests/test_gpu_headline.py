@@ -366,7 +366,7 @@ def test_two_pass_long_transforms(dsc, dt, n):
     for rows in (1, 5):
         x = rng.standard_normal((rows, n)).astype(dt)
         X = dsc.rfft(dsc.from_numpy(x))
-        fused = n == 131072                                  # fft_xcd_fused.hip: one launch, intermediate in the XCD-local L2
+        fused = n == 131072 or (dt == np.float64 and n == 65536)      # fft_xcd_fused.hip: one launch, intermediate in the XCD-local L2
         assert dsc.last_fft_path() == ('r2c_fused_l2' if fused else 'r2c_2pass_regs')
         got = X.numpy()
         assert_close(got[rows - 1], port.rfft(x[rows - 1]), what=f'rfft {np.dtype(dt).name} n={n}')
@@ -501,7 +501,7 @@ def test_every_element_of_the_f64_paths_with_128_bit_stores(dsc):
     def worst(got, want):
         return float(np.max(np.abs(got - want) / np.max(np.abs(want), axis=1, keepdims=True)))
 
-    for n, rows in ((4096, 2048), (65536, 128)):
+    for n, rows in ((4096, 2048), (524288, 12)):
         xd = rng.standard_normal((rows, n))
         wd = np.fft.rfft(xd, axis=-1)
         zd = rng.standard_normal((rows, n // 2)) + 1j * rng.standard_normal((rows, n // 2))
@@ -528,7 +528,7 @@ def test_fused_l2_paired_teams_every_element(dsc):
     found two such bugs: a team overwriting its own intermediate after its partner had left, and 128-bit store data rewritten by
     the next multiply).  3 rows: teams with and without work; 40: several rows per team."""
     rng = np.random.default_rng(262)
-    for rows, L in ((3, 131072), (40, 131072), (70, 65536)):
+    for rows, L in ((3, 131072), (40, 131072), (70, 65536), (150, 32768)):
         z = rng.standard_normal((rows, L)) + 1j * rng.standard_normal((rows, L))
         x = rng.standard_normal((rows, 2 * L))
         wf, wi, wr = np.fft.fft(z, axis=-1), np.fft.ifft(z, axis=-1), np.fft.rfft(x, axis=-1)
@@ -554,13 +554,13 @@ def test_two_pass_padded_rows(dsc, dt, n):
     for rows, ls in ((3, n - 1), (2, n // 2 + 3), (2, n + 64)):
         x = rng.standard_normal((rows, ls)).astype(dt)
         got = dsc.rfft(dsc.from_numpy(x), n=n)
-        assert dsc.last_fft_path() == ('r2c_fused_l2' if n in (131072, 262144) else 'r2c_2pass_regs')
+        assert dsc.last_fft_path() == 'r2c_fused_l2'           # every length of this test is on the team kernel by now
         assert_close(got.numpy()[rows - 1], port.rfft(x[rows - 1], n), what=f'padded 2-pass rfft n={n} ls={ls}')
     bins = n // 2 + 1
     for rows, lb in ((2, bins - 5), (3, bins + 9)):
         Y = (rng.standard_normal((rows, lb)) + 1j * rng.standard_normal((rows, lb))).astype(cdt)
         b = dsc.irfft(dsc.from_numpy(Y), n=bins)
-        assert dsc.last_fft_path() == ('c2r_fused_l2' if n in (131072, 262144) else 'c2r_2pass_regs')
+        assert dsc.last_fft_path() == 'c2r_fused_l2'
         assert_close(b.numpy()[0], port.irfft(Y[0], bins), what=f'padded 2-pass irfft bins={bins} lb={lb}')
 
 
@@ -574,7 +574,7 @@ def test_two_pass_complex_transforms(dsc, dt, L):
     for rows, ls in ((1, L), (3, L), (2, L - 77), (2, L + 5)):
         z = (rng.standard_normal((rows, ls)) + 1j * rng.standard_normal((rows, ls))).astype(dt)
         Z = dsc.fft(dsc.from_numpy(z), n=L)
-        path = 'c2c_fused_l2' if (L == 65536 or (dt == np.complex128 and L == 131072)) else 'c2c_2pass_regs'
+        path = 'c2c_fused_l2' if (L == 65536 or dt == np.complex128) else 'c2c_2pass_regs'
         assert dsc.last_fft_path() == path
         zh = Z.numpy()
         assert_close(zh[rows - 1], port.fft(z[rows - 1], L), what=f'fft L={L} ls={ls}')

@@ -78,6 +78,9 @@ CASES['fft_c64_131072'] = _fft_case(131072, 2048, f64=True)
 CASES['ifft_c64_131072'] = _fft_case(131072, 2048, f64=True, inverse=True)
 CASES['ifft_c32_65536'] = _fft_case(65536, 4096, inverse=True)
 CASES['rfft_f64_131072'] = _rfft_case(131072, 2048, f64=True)
+CASES['rfft_f64_65536'] = _rfft_case(65536, 4096, f64=True)
+CASES['irfft_f64_65536'] = _rfft_case(65536, 4096, f64=True, inverse=True)
+CASES['fft_c64_32768'] = _fft_case(32768, 4096, f64=True)
 CASES['irfft_f64_131072'] = _rfft_case(131072, 2048, f64=True, inverse=True)
 
 

@@ -1,11 +1,11 @@
-"""tools/stress_fused.py — repeated runs of the paired-team transforms (f64, 65536- and 131072-point rows) against numpy; prints the rows that differ."""
+"""tools/stress_fused.py — repeated runs of the paired-team transforms (f64, 32768-, 65536- and 131072-point rows) against numpy; prints the rows that differ."""
 import sys, numpy as np
 sys.path.insert(0, '.')
 import dsc_amd as dsc
 dsc.init(6 << 30, 1 << 30)
 rng = np.random.default_rng(11)
 bad = 0
-for rows, L in ((3, 131072), (17, 131072), (40, 131072), (100, 131072), (5, 65536), (90, 65536), (200, 65536)):
+for rows, L in ((3, 131072), (17, 131072), (40, 131072), (100, 131072), (5, 65536), (90, 65536), (200, 65536), (3, 32768), (70, 32768), (300, 32768)):
     z = rng.standard_normal((rows, L)) + 1j * rng.standard_normal((rows, L))
     wf, wi = np.fft.fft(z, axis=-1), np.fft.ifft(z, axis=-1)
     x = rng.standard_normal((rows, 2 * L))
