@@ -7,15 +7,19 @@
 //   cols  Z[256 k1 + k2] = sum_{j1} A[j1][k2] W_256^{j1 k1}                     256-point FFTs, tasks of 16 columns k2
 //   X from Z by the packed-real pass (dsc_fft.h:199-225), fused into the column task
 //
-// A task is 4096 complex = 256 threads x 16 values (256 = 16 x 16: two in-register 16-point passes and one LDS exchange).
-// A row is 16 row tasks, then 16 column tasks, by a TEAM of 16 persistent workgroups that run on the same XCD
-// (HW_REG_XCC_ID), so that the 512 KiB (f32) of A they write and read back stay in that XCD's 4 MiB L2:
+// A task is 16 values per thread of a 256-thread (f64) or 512-thread (f32) workgroup: 4096 / 8192 complex, i.e. 16 / 32 adjacent
+// lines of a row task (L2 = 256; L2 = 128, 512: twice / half as many) and 16 / 32 columns of a column task — pieces of at least
+// 128 B on the external side.  256 = 16 x 16: two in-register 16-point passes and one LDS exchange.  A row is L2 / 16 (f64) or
+// L2 / 32 (f32) row tasks, then as many column tasks, by a TEAM of that many persistent workgroups that run on the same XCD
+// (HW_REG_XCC_ID), so that the 512 KiB .. 2 MiB of A they write and read back stay in that XCD's 4 MiB L2:
 //   * teams form at kernel start from the order in which workgroups of one XCD arrive (a counter per XCD), after one
-//     grid-wide arrival count; the launch is sized to be fully resident;
+//     grid-wide arrival count; the launch is sized to be fully resident (two workgroups per CU);
 //   * the team barrier is a counter in the XCD's own L2 — plain atomics, no agent-scope fence, hence no L2 write-back /
 //     invalidate; A is written with ordinary stores (the L1 is write-through) and read with sc1 loads (miss the L1);
+//   * teams work in PAIRS that share one scratch row and take turns on it (see below): few rows of A are live per XCD, yet
+//     there is always a second team to fill a team's waits;
 //   * rows are claimed from a global counter by the team's first workgroup and published at a barrier; the next row's samples
-//     are requested while the team waits at the first barrier of the current one;
+//     are requested during the second task of the current one;
 //   * every spin is bounded: a barrier that does not complete writes a code to a pinned host word (the host aborts at the next synchronise).
 // Measured skeleton and the L2 behaviour behind this design: tools/xcdbench.hip, profiles/r02_c5_infinity_cache.md section 3.
 // Reference: dsc_rfft / dsc_irfft / dsc_fft / dsc_ifft (dsc/src/dsc.cpp:1958-2260, dsc_fft.h:57-238).
@@ -29,14 +33,8 @@
 
 namespace {
 
-constexpr int kNT = 256;                  // threads per workgroup
 constexpr int kMaxTeams = 8;              // teams per XCD
 constexpr int kPQ = 276, kPK = 17;        // row-task exchange: line pitch (values), k2' pitch
-// (experiment: pairs for f32 as well, at four workgroups per CU — 128 VGPRs fit — measured rfft 1.44-1.47 vs 1.47-1.49 ms, fft 1.28 vs
-// 1.14-1.17 ms: not adopted)
-#ifndef DSC_FUSED_F32_PAIRED
-#define DSC_FUSED_F32_PAIRED 0
-#endif
 #ifndef DSC_FUSED_BINS_LOAD
 #define DSC_FUSED_BINS_LOAD kCached
 #endif
@@ -129,24 +127,27 @@ __device__ __forceinline__ void four_step_twiddle16(cpx<R> (&v)[16], const cpx<R
 // REAL: dsc_rfft (forward) / dsc_irfft (INV).  !REAL: dsc_fft / dsc_ifft of complex rows.
 // ext  = the time-domain side (forward input, inverse output): row pitch ext_pitch_b bytes, ext_len_b valid bytes
 // bins = the frequency-domain side: row pitch bins_pitch bins, bins_len valid bins
-// L2 = 256 or 512: the row-task transform length (L = 256 L2); TS = L2 / 16 workgroups per team.
-template<typename R, bool REAL, bool INV, int L2>
-__global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? (DSC_FUSED_F32_PAIRED ? 4 : 3) : 2)) void fused_l2_kernel(const char *__restrict__ ext, char *__restrict__ ext_out,
+// L2 = 128, 256 or 512: the row-task transform length (L = 256 L2).  kNT = 256 threads (tasks of 4096 complex, 16 columns) or 512
+// (8192 complex, 32 columns: f32 rows of 131072 points, whose pieces would be 64 B otherwise); TS = L2 / (kNT / 16) workgroups
+// per team.
+template<typename R, bool REAL, bool INV, int L2, int kNT>
+__global__ __launch_bounds__(kNT, (kNT == 512 ? 4 : 2)) void fused_l2_kernel(const char *__restrict__ ext, char *__restrict__ ext_out,
                                                                                const cpx<R> *__restrict__ bins_in, cpx<R> *__restrict__ bins_out,
                                                                                cpx<R> *scratch, fused_ctl *ctl, unsigned *host_error, int rows, int teams_cap,
                                                                                const cpx<R> *__restrict__ twL, const cpx<R> *__restrict__ tw_real, R scale,
                                                                                long long ext_pitch_b, int ext_len_b, long long bins_pitch, int bins_len) {
     using C = cpx<R>;
-    constexpr int CB = (int) sizeof(C), L = 256 * L2, NC = 16, H = 8;
-    constexpr int kTS = L2 / 16;                                    // tasks per phase = workgroups per team
-    constexpr int LINES = 4096 / L2, TPL = L2 / 16;                 // row task: lines per task, threads per line
+    constexpr int CB = (int) sizeof(C), L = 256 * L2, NC = kNT / 16, H = NC / 2;
+    constexpr int kTS = L2 / NC;                                    // tasks per phase = workgroups per team
+    constexpr int LINES = 16 * kNT / L2, TPL = L2 / 16;             // row task: lines per task, threads per line
     constexpr int kPQ5 = 532, kPK5 = 33;                            // row-task exchange of the 512-point lines
     constexpr int BL = REAL ? DSC_FUSED_BINS_LOAD : kStream;                    // spectrum rows of the real transforms are skewed: fft_r2c_2pass.hip
     // ... and written in 64-B pieces that straddle sectors: with the default policy the pieces of the 16 column tasks of a row
     // (same XCD, same moment) meet in the L2 and leave as whole lines
     constexpr int BS = REAL ? DSC_FUSED_BINS_STORE : kStream;
     constexpr int kPQ1 = 148, kPK1 = 9;                             // ... of the 128-point lines (32 lines)
-    __shared__ __attribute__((aligned(16))) R plane[L2 == 128 ? 32 * kPQ1 : 16 * kPQ];      // row task: LINES x pitch; column task: [k1][ell] 257 x 16
+    constexpr int kPlaneRows = LINES * (L2 == 128 ? kPQ1 : L2 == 256 ? kPQ : kPQ5), kPlaneCols = 257 * NC;
+    __shared__ __attribute__((aligned(16))) R plane[kPlaneRows > kPlaneCols ? kPlaneRows : kPlaneCols];      // row task: LINES x pitch; column task: [k1][ell] 257 x NC
     constexpr int TAB = L2 > 256 ? L2 : 256;                        // W_TAB^m: W_256^m = wtab[W1 m], W_L2^m = wtab[W2 m]
     __shared__ C wtab[TAB];
     __shared__ int info[8];
@@ -175,18 +176,16 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? (DSC_FUSED_F32_PAIRED ? 4 : 
     if (team >= __builtin_amdgcn_readfirstlane(info[3]) || team >= kMaxTeams || team >= teams_cap) return;               // workgroups that do not fill a team
     // Counters of a team (one 256-B block in the XCD's L2): [0] arrivals at "A is written", [4] / [5] published rows, [8] arrivals
     // at "A has been read", [12] members that have left.
-    // PAIRED (f64: 1 or 2 MiB of A per row, and the 4 MiB L2 also carries the streams): teams 2p and 2p + 1 of an XCD share one
-    // scratch row and take turns — a team may write A only once its partner has read its own; while one team is in its
-    // write -> barrier -> read window the other computes its column task and the next row task.  Two workgroups per CU; per XCD
-    // one row of A is live at L = 131072 (one pair), two at L = 65536 (two pairs).  Measured against unpaired teams with a row
-    // each: c64 L = 65536 1.31 -> 1.07 ms, rfft f64 N = 131072 1.52 -> 1.20 ms, config 5 3.37 -> 3.0-3.2 ms; in f32 (six teams of
-    // 16 per XCD already overlap) pairing is a wash (rfft +5 %, fft -12 %) and is not used.
-    constexpr bool PAIRED = sizeof(R) == 8 || DSC_FUSED_F32_PAIRED;
+    // PAIRS.  A row of A is 512 KiB .. 2 MiB and the 4 MiB L2 also carries the streams, so the L2 has room for few rows — too few
+    // teams to hide a team's barrier chain if every team owned one.  Teams 2p and 2p + 1 of an XCD therefore SHARE one scratch row
+    // and take turns: a team may write A only once its partner has read its own; while one team is in its write -> barrier ->
+    // read window the other computes its column task and the next row task.  Two workgroups per CU.  Measured against teams with
+    // a row each: c64 L = 65536 1.31 -> 1.07 ms, rfft f64 N = 131072 1.52 -> 1.20 ms, config 5 3.37 -> 3.0-3.2 ms.
     unsigned *tb = &ctl->team[xcc * kMaxTeams + team][0];
     const int n_teams = __builtin_amdgcn_readfirstlane(info[3]) < teams_cap ? __builtin_amdgcn_readfirstlane(info[3]) : teams_cap;
-    const bool has_partner = PAIRED && (team ^ 1) < n_teams && (team ^ 1) < kMaxTeams;
+    const bool has_partner = (team ^ 1) < n_teams && (team ^ 1) < kMaxTeams;
     unsigned *pb = &ctl->team[xcc * kMaxTeams + (team ^ 1)][0];
-    C *scr = scratch + (size_t) (xcc * teams_cap + (PAIRED ? team >> 1 : team)) * L;
+    C *scr = scratch + (size_t) (xcc * teams_cap + (team >> 1)) * L;
     const __amdgpu_buffer_rsrc_t rwork = __builtin_amdgcn_make_buffer_rsrc((void *) scr, 0, L * CB, 0x00020000);
     unsigned target = 0;
     bool broken = false;
@@ -250,12 +249,12 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? (DSC_FUSED_F32_PAIRED ? 4 : 
     const int zoff = ((LINES * rank + wq) + 256 * ws) * CB;    // REAL: z[j] = (x[2j], x[2j + 1])
     const int aoff = ((LINES * rank + rq) * L2 + rtau) * CB;
     const int j1r = LINES * rank + rq;
-    // PAIRED: the seven table values of the inter-pass twiddle are re-read per row (L2 hits) instead of living in 28 registers
-    auto opaque_j1 = [&]() { int j = j1r; if constexpr (PAIRED) asm volatile("" : "+v"(j)); return j; };
+    // the seven table values of the inter-pass twiddle are re-read per row (L2 hits) instead of living in 14 / 28 registers
+    auto opaque_j1 = [&]() { int j = j1r; asm volatile("" : "+v"(j)); return j; };
     constexpr int ZSTEP = TPL * 256 * CB, ASTEP = TPL * CB;
     // column task `rank`: lanes tid = 16 t + ell: column ell (REAL: 8 columns 8 b + 1 .. 8 b + 8 and their mirrors; column 0
     // takes the place of the duplicate 128 in the last block), slice t of the 256-point axis (j1 = t + 16 i; k1 = t + 16 k)
-    const int ell = tid & 15, t = tid >> 4;
+    const int ell = tid % NC, t = tid / NC;
     const bool last = rank == kTS - 1;
     const bool col0 = REAL && last && ell == H;
     const int col = !REAL ? NC * rank + ell : col0 ? 0 : ell < H ? H * rank + 1 + ell : L2 - H - H * rank + (ell - H);
@@ -282,26 +281,12 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? (DSC_FUSED_F32_PAIRED ? 4 : 
         }
     };
 
-    // Second barrier of a row, split: ARRIVE as soon as this workgroup's reads of A have landed (they return in order, ahead of
-    // the 16 or 17 loads of the next row requested right behind them), WAIT only before the next row's A is stored — the
-    // barrier's latency hides behind the column task and the next row task.
+    // "this workgroup has read A": the partner may overwrite it as soon as the whole team has arrived, so wait for the reads
+    // themselves.  (The next row is requested in the middle of the second task, once the registers that held A are free: at two
+    // workgroups per CU there are 256 (f64) / 128 (f32, 512 threads) per lane.)
     auto release_scratch = [&]() {
-        if constexpr (PAIRED) {
-            // the partner may overwrite A as soon as this team has arrived: wait for the reads themselves, then ask for the next row
-            // (the next row is requested in the middle of the second task, once the registers that held A are free: at two
-            // workgroups per CU there are 256 per lane)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            arrive_read();
-        } else {
-            // the request goes out right behind the reads of A, which return first (in order): 16 (17) loads may stay in flight.
-            // (Relies on no other vector memory instruction in between — the kernels of this form have no spills; the fences keep
-            // the compiler from moving the request ahead of the reads.)
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if (next < rows) { request(cur, cur_last, next); __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
-            else             { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-            arrive_read();
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        arrive_read();
     };
 
     // ---- the first two rows of this team
@@ -327,6 +312,9 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? (DSC_FUSED_F32_PAIRED ? 4 : 
 #endif
     for (int it = 0; row < rows; ++it) {
         PMARK(0);
+        // the previous row's last reads of the LDS plane (packed-real partners, or the second task's exchange) carry no barrier of
+        // their own: no wave may start writing the plane for this row before every wave is done with it
+        lds_barrier();
         const int slot = it & 1;                                    // slot of `row`: free once everyone holds `row` and `next`
         C u[16], v[16];
         if constexpr (!INV) {
@@ -442,7 +430,7 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? (DSC_FUSED_F32_PAIRED ? 4 : 
                 for (int tp = 0; tp < 16; ++tp) u[tp].y = xr[tp * NC];
                 lds_barrier();
             }
-            if constexpr (PAIRED) { if (next < rows) request(cur, cur_last, next); }    // v is dead: its registers take the next row
+            if (next < rows) request(cur, cur_last, next);          // v is dead: its registers take the next row
             dft16<R, false>(u);                                     // over t' -> k: u[p] = Z[k1 = t + 16 brev(p)][col]
             if constexpr (!REAL) {
 #pragma unroll
@@ -623,8 +611,8 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? (DSC_FUSED_F32_PAIRED ? 4 : 
 #pragma unroll
             for (int m = 0; m < 16; ++m) st<kStream>(u[brev(m, 4)], ro, zoff, m * ZSTEP);
             __builtin_amdgcn_sched_barrier(0);
-            // PAIRED: the inverse has no registers to spare in its second task (requesting earlier spills 50 of them and costs 30 %)
-            if constexpr (PAIRED) { if (next < rows) request(cur, cur_last, next); }
+            // the inverse has no registers to spare in its second task (requesting earlier spills 50 of them and costs 30 %)
+            if (next < rows) request(cur, cur_last, next);
         }
         PMARK(6);
         // the row after next was published in `slot` at the first barrier of this row
@@ -642,22 +630,30 @@ __global__ __launch_bounds__(kNT, (sizeof(R) == 4 ? (DSC_FUSED_F32_PAIRED ? 4 : 
 // workgroups per CU the launch asks for, and the rows of scratch that implies (one per possible team, + 1 per XCD of slack for an
 // uneven dispatch).  f32 rows of 512 KiB: six teams per XCD (3 MiB of its 4 MiB L2); f64: two workgroups per CU, teams in pairs
 // that share a row (1 MiB rows: four teams, 2 MiB: two).
-constexpr int wg_per_cu(int L, bool single_precision) { (void) L; return single_precision ? (DSC_FUSED_F32_PAIRED ? 4 : 3) : 2; }
-constexpr int teams_cap_of(int L, bool single_precision) { return wg_per_cu(L, single_precision) * 32 / (L / 256 / 16) + 1; }
+// f32: 512-thread tasks (8192 complex: 32 / 16 lines, 32 columns) — with 256 threads the spectrum pieces of a column task are 64 B
+// (measured at L = 65536: rfft 1.48 -> 1.34 ms, irfft 1.59 -> 1.48 ms, fft 1.18 -> 1.15 ms; at 131072 the 256-thread form loses to
+// the two-kernel route).  f64: 256 threads (the same pieces in bytes).
+constexpr int threads_of(int L, bool single_precision) { (void) L; return single_precision ? 512 : 256; }
+constexpr int wg_per_cu(int L, bool single_precision) { (void) L; (void) single_precision; return 2; }     // teams work in pairs
+constexpr int team_size_of(int L, bool single_precision) { return (L / 256) / (threads_of(L, single_precision) / 16); }
+constexpr int teams_cap_of(int L, bool single_precision) {
+    return wg_per_cu(L, single_precision) * 32 / team_size_of(L, single_precision) + 1;       // workgroups per XCD (32 CUs) / team size
+}
 
-template<typename R, bool REAL, bool INV, int L2>
+template<typename R, bool REAL, bool INV, int L2, int NT>
 bool launch_one(const void *in, void *out, long long rows, void *scratch, unsigned *host_error, const void *tw_full, const void *tw_real, double scale,
                 long long ext_pitch_b, int ext_len_b, long long bins_pitch, int bins_len, hipStream_t stream) {
     using C = cpx<R>;
-    constexpr int TS = L2 / 16, L = 256 * L2;
+    constexpr int L = 256 * L2, TS = team_size_of(L, sizeof(R) == 4);
     constexpr int cap = teams_cap_of(L, sizeof(R) == 4);
+    static_assert(NT == threads_of(L, sizeof(R) == 4), "thread count of this length");
     static int grids[64];                                       // resident launch size per device (0 = not asked yet, -1 = does not fit)
     int dev = 0;
     DSC_KERNEL_CHECK(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return false;
     if (grids[dev] == 0) {
         int per_cu = 0, cus = 0;
-        DSC_KERNEL_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *) fused_l2_kernel<R, REAL, INV, L2>, kNT, 0));
+        DSC_KERNEL_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *) fused_l2_kernel<R, REAL, INV, L2, NT>, NT, 0));
         DSC_KERNEL_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         if (per_cu > wg_per_cu(L, sizeof(R) == 4)) per_cu = wg_per_cu(L, sizeof(R) == 4);
         int g = cus * per_cu;
@@ -669,7 +665,7 @@ bool launch_one(const void *in, void *out, long long rows, void *scratch, unsign
     fused_ctl *ctl = (fused_ctl *) scratch;
     C *rowsbuf = (C *) ((char *) scratch + dsc_fft_fused_l2_ctl_bytes());
     DSC_KERNEL_CHECK(hipMemsetAsync(ctl, 0, sizeof(fused_ctl), stream));
-    DSC_LAUNCH((fused_l2_kernel<R, REAL, INV, L2>), dim3((unsigned) grids[dev]), dim3(kNT), 0, stream, INV ? (const char *) nullptr : (const char *) in,
+    DSC_LAUNCH((fused_l2_kernel<R, REAL, INV, L2, NT>), dim3((unsigned) grids[dev]), dim3(NT), 0, stream, INV ? (const char *) nullptr : (const char *) in,
                INV ? (char *) out : (char *) nullptr, INV ? (const C *) in : (const C *) nullptr, INV ? (C *) nullptr : (C *) out, rowsbuf, ctl, host_error, (int) rows,
                cap, (const C *) tw_full, (const C *) tw_real, (R) scale, ext_pitch_b, ext_len_b, bins_pitch, bins_len);
     return true;
@@ -686,7 +682,7 @@ bool dsc_fft_fused_l2_supports(int L, bool single_precision, bool real, bool inv
     if (L == 65536) return true;
     if (L == 32768) return !single_precision;          // f32 has its own one-pass kernels at this length
     (void) real; (void) inverse;
-    return L == 131072 && !single_precision;
+    return L == 131072;                                // f64: config 5 (256-thread tasks); f32: 512-thread tasks (16 lines / 32 columns)
 }
 
 // bytes of scratch a launch needs: the control block + one row of A per possible team
@@ -694,19 +690,19 @@ size_t dsc_fft_fused_l2_scratch_bytes(int L, bool single_precision) {
     return dsc_fft_fused_l2_ctl_bytes() + (size_t) 8 * teams_cap_of(L, single_precision) * L * (single_precision ? 8 : 16);
 }
 
-template<typename R, int L2>
+template<typename R, int L2, int NT = 256>
 static bool launch_any(const void *in, void *out, long long rows, bool real, bool inverse, void *scratch, unsigned *host_error, const void *tw_full,
                        const void *tw_real, long long in_pitch, int in_len, hipStream_t stream) {
     constexpr long long CBl = 2 * sizeof(R);
     constexpr int L = 256 * L2;
     const double inv_scale = 1.0 / (double) L;                              // dsc_fft.h:232 (2 / 2n) and :168-175
     if (real) {
-        if (!inverse) return launch_one<R, true, false, L2>(in, out, rows, scratch, host_error, tw_full, tw_real, 1.0, in_pitch * (long long) sizeof(R), (int) (in_len * sizeof(R)),
+        if (!inverse) return launch_one<R, true, false, L2, NT>(in, out, rows, scratch, host_error, tw_full, tw_real, 1.0, in_pitch * (long long) sizeof(R), (int) (in_len * sizeof(R)),
                                                             (long long) L + 1, L + 1, stream);
-        return launch_one<R, true, true, L2>(in, out, rows, scratch, host_error, tw_full, tw_real, inv_scale, (long long) L * CBl, (int) (L * CBl), in_pitch, in_len, stream);
+        return launch_one<R, true, true, L2, NT>(in, out, rows, scratch, host_error, tw_full, tw_real, inv_scale, (long long) L * CBl, (int) (L * CBl), in_pitch, in_len, stream);
     }
-    if (!inverse) return launch_one<R, false, false, L2>(in, out, rows, scratch, host_error, tw_full, tw_full, 1.0, in_pitch * CBl, (int) (in_len * CBl), (long long) L, L, stream);
-    return launch_one<R, false, true, L2>(in, out, rows, scratch, host_error, tw_full, tw_full, inv_scale, (long long) L * CBl, (int) (L * CBl), in_pitch, in_len, stream);
+    if (!inverse) return launch_one<R, false, false, L2, NT>(in, out, rows, scratch, host_error, tw_full, tw_full, 1.0, in_pitch * CBl, (int) (in_len * CBl), (long long) L, L, stream);
+    return launch_one<R, false, true, L2, NT>(in, out, rows, scratch, host_error, tw_full, tw_full, inv_scale, (long long) L * CBl, (int) (L * CBl), in_pitch, in_len, stream);
 }
 
 // Same arguments as dsc_launch_rfft_two_pass / dsc_launch_fft_two_pass (real = packed-real transform).  Returns false when the
@@ -715,8 +711,9 @@ bool dsc_launch_fft_fused_l2(const void *in, void *out, long long rows, int L, b
                              unsigned *host_error, const void *tw_full, const void *tw_real, long long in_pitch, int in_len, hipStream_t stream) {
     if (rows <= 0) return true;
     if (!dsc_fft_fused_l2_supports(L, single_precision, real, inverse) || rows > 0x7fffff00) return false;
+    if (L == 131072 && single_precision) return launch_any<float, 512, 512>(in, out, rows, real, inverse, scratch, host_error, tw_full, tw_real, in_pitch, in_len, stream);
     if (L == 131072) return launch_any<double, 512>(in, out, rows, real, inverse, scratch, host_error, tw_full, tw_real, in_pitch, in_len, stream);
     if (L == 32768) return launch_any<double, 128>(in, out, rows, real, inverse, scratch, host_error, tw_full, tw_real, in_pitch, in_len, stream);
-    return single_precision ? launch_any<float, 256>(in, out, rows, real, inverse, scratch, host_error, tw_full, tw_real, in_pitch, in_len, stream)
+    return single_precision ? launch_any<float, 256, 512>(in, out, rows, real, inverse, scratch, host_error, tw_full, tw_real, in_pitch, in_len, stream)
                             : launch_any<double, 256>(in, out, rows, real, inverse, scratch, host_error, tw_full, tw_real, in_pitch, in_len, stream);
 }
