@@ -124,7 +124,7 @@ void   dsc_launch_fft_two_pass(const void *in, void *out, long long rows, int L,
 void   dsc_launch_rfft_two_pass(const void *in, void *out, long long rows, int L, bool inverse, bool single_precision, void *work,
                                 const void *tw_full, const void *tw_real, long long in_pitch, int in_len, hipStream_t stream);
 
-// ---- complex rows of 65536 points (f32, f64), 32768 and 131072 points (f64; the latter = config 5) in one launch with the four-step intermediate in the XCD-local L2
+// ---- complex rows of 65536 and 131072 points (f32, f64; the f64 131072 = config 5) and 32768 points (f64) in one launch with the four-step intermediate in the XCD-local L2
 // (fft_xcd_fused.hip).  Arguments as the two-pass launchers; `scratch`: dsc_fft_fused_l2_scratch_bytes() bytes, of which the
 // first dsc_fft_fused_l2_ctl_bytes() are the control block; host_error: a pinned, device-visible word that receives a non-zero
 // code if a barrier of the launch did not complete.  Returns false when the launch cannot be made fully resident on this device.
