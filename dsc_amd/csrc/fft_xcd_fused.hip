@@ -35,6 +35,12 @@ namespace {
 
 constexpr int kMaxTeams = 8;              // teams per XCD
 constexpr int kPQ = 276, kPK = 17;        // row-task exchange: line pitch (values), k2' pitch
+#ifndef DSC_FUSED_EXT_LOAD
+#define DSC_FUSED_EXT_LOAD kStream
+#endif
+#ifndef DSC_FUSED_EXT_STORE
+#define DSC_FUSED_EXT_STORE kStream
+#endif
 #ifndef DSC_FUSED_BINS_LOAD
 #define DSC_FUSED_BINS_LOAD kCached
 #endif
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(kNT, (kNT == 512 ? 4 : 2)) void fused_l2_kernel(con
         if constexpr (!INV) {
             const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *) (ext + (size_t) row * ext_pitch_b), 0, ext_len_b, 0x00020000);
 #pragma unroll
-            for (int m = 0; m < 16; ++m) dst[m] = buf_load<kStream>(r, zoff, m * ZSTEP, R{});
+            for (int m = 0; m < 16; ++m) dst[m] = buf_load<DSC_FUSED_EXT_LOAD>(r, zoff, m * ZSTEP, R{});
         } else {
             const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *) (bins_in + (size_t) row * bins_pitch), 0, bins_len * CB, 0x00020000);
 #pragma unroll
@@ -609,7 +615,7 @@ __global__ __launch_bounds__(kNT, (kNT == 512 ? 4 : 2)) void fused_l2_kernel(con
             for (int m = 0; m < 16; ++m) u[m] = C{u[m].x * scale, u[m].y * scale};
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int m = 0; m < 16; ++m) st<kStream>(u[brev(m, 4)], ro, zoff, m * ZSTEP);
+            for (int m = 0; m < 16; ++m) st<DSC_FUSED_EXT_STORE>(u[brev(m, 4)], ro, zoff, m * ZSTEP);
             __builtin_amdgcn_sched_barrier(0);
             // the inverse has no registers to spare in its second task (requesting earlier spills 50 of them and costs 30 %)
             if (next < rows) request(cur, cur_last, next);
