@@ -568,9 +568,10 @@ def test_fused_l2_f32_every_element(dsc):
     dsc.synchronize()
 
 
-@pytest.mark.parametrize('dt,n', [(np.float32, 131072), (np.float64, 65536), (np.float64, 262144)])
+@pytest.mark.parametrize('dt,n', [(np.float32, 131072), (np.float32, 262144), (np.float64, 65536), (np.float64, 131072), (np.float64, 262144)])
 def test_two_pass_padded_rows(dsc, dt, n):
-    """Zero padded / cropped rows on the two-pass kernels (the row descriptors end at the last valid sample / bin)."""
+    """Zero padded / cropped rows on the long-row kernels — every form of the team kernel (fft_xcd_fused.hip), which replaced the two-pass
+    kernels at these lengths: the row descriptors end at the last valid sample / bin."""
     from oracle import port
     cdt = np.complex64 if dt == np.float32 else np.complex128
     rng = np.random.default_rng(n + 5)
