@@ -46,7 +46,10 @@ constexpr int kBinsLoadReal = DSC_2PASS_BINS_LOAD_POLICY;
 constexpr int kPQ = 1060;                    // rows kernel: plane pitch per line (values), = 4 mod 32: conflict-free both ways
 
 template<typename R> constexpr int rows_lds_bytes() { return (16 * kPQ + 2 * 1024) * (int) sizeof(R); }          // plane + W_1024
-template<typename R, int B1> constexpr int cols_lds_bytes() { return (16384 + 2 * 32 * B1 + 512) * (int) sizeof(R); }  // plane + W_L1 + slack: the unused partner read of bin 0 lands one row past the plane
+// threads of the column kernel: 512, or 1024 for f32 with L1 = 256 (N = 524288) — with 512 its runs are 32 columns = 256 B,
+// skewed on the spectrum side (measured 1.33 ms for that kernel against 0.78 ms for the rows kernel of the same transform)
+template<typename R, int B1> constexpr int cols_threads() { return (sizeof(R) == 4 && B1 == 8) ? 1024 : 512; }
+template<typename R, int B1> constexpr int cols_lds_bytes() { return (32 * cols_threads<R, B1>() + 2 * 32 * B1 + cols_threads<R, B1>()) * (int) sizeof(R); }  // plane + W_L1 + slack: the unused partner read of bin 0 lands one row past the plane
 template<typename R> constexpr int waves_per_eu() { return sizeof(R) == 8 ? 2 : 4; }     // f32: <= 128 VGPRs, two workgroups per CU
 
 // W_L^{j1 (tau + 32 k3)}, k3 = 4 a + b: base W_L^{j1 tau} times A[a] = W_L^{128 j1 a} times Bq[b] = W_L^{32 j1 b}, all three
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(512, (waves_per_eu<R>())) void two_pass_rows_kernel
 // bases back into one and materialises an address register for every offset beyond 64 KiB).
 template<typename R, int B1>
 struct stage_ptrs {
-    static constexpr int NC = 512 / B1, L1 = 32 * B1, HALF = L1 / 2;
+    static constexpr int NC = cols_threads<R, B1>() / B1, L1 = 32 * B1, HALF = L1 / 2;
     R *mine_lo, *mine_hi;
     const R *theirs_lo, *theirs_hi;
     __device__ __forceinline__ stage_ptrs(R *plane, int t, int ell, int ellp, bool col0) {
@@ -182,17 +185,17 @@ struct stage_ptrs {
 //   element e = B1 i' + p of a thread after the transform: k1 = t + B1 i' + 32 k3, k3 = brev(p)
 //   REAL = false: plain complex transform (dsc_fft / dsc_ifft): columns NC b + ell, no pairing, rows of L bins
 template<typename R, int B1, bool INV, bool REAL>
-__global__ __launch_bounds__(512, (waves_per_eu<R>())) void two_pass_cols_kernel(const cpx<R> *__restrict__ in, cpx<R> *__restrict__ out,
+__global__ __launch_bounds__((cols_threads<R, B1>()), (waves_per_eu<R>())) void two_pass_cols_kernel(const cpx<R> *__restrict__ in, cpx<R> *__restrict__ out,
                                                                               const cpx<R> *__restrict__ twL, const cpx<R> *__restrict__ tw_real,
                                                                               long long bins_pitch, int bins_len) {
     using C = cpx<R>;
     constexpr int L1 = 32 * B1, L = L1 * 1024, CB = (int) sizeof(C);
-    constexpr int NC = 512 / B1, H = NC / 2, BLOCKS = 1024 / NC, CPT = 32 / B1, LOGB = ilog2(B1);
+    constexpr int NC = cols_threads<R, B1>() / B1, H = NC / 2, BLOCKS = 1024 / NC, CPT = 32 / B1, LOGB = ilog2(B1);
     constexpr int WSTEP = B1 * 1024 * CB;                 // work[(B1 i + t)][col]: + i * B1 rows
     constexpr int BSTEP = 1024 * CB;                      // bin 1024 k1 + col:     + k1 * 1024 bins
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     R *plane = (R *) lds_raw;
-    C *wl1 = (C *) (plane + 16384);
+    C *wl1 = (C *) (plane + 32 * cols_threads<R, B1>());
     const int tid = threadIdx.x;
     if (tid < L1) wl1[tid] = twL[tid * 1024];                                 // W_L1^m = W_L^{1024 m}
     const long long row = blockIdx.x / BLOCKS;
@@ -368,17 +371,19 @@ void launch_pair(const void *in, void *out, long long rows, void *work, const vo
         DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) two_pass_cols_kernel<R, B1, false, REAL>, hipFuncAttributeMaxDynamicSharedMemorySize, cl));
         DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) two_pass_cols_kernel<R, B1, true, REAL>, hipFuncAttributeMaxDynamicSharedMemorySize, cl));
     }
-    const dim3 grid((unsigned) (rows * 2 * B1));          // L1 / 16 row groups = 1024 / NC column blocks = 2 B1 per transform
+    const dim3 grid((unsigned) (rows * 2 * B1));          // L1 / 16 row groups per transform
+    constexpr int CT = cols_threads<R, B1>();
+    const dim3 cgrid((unsigned) (rows * (1024 / (CT / B1))));   // 1024 / NC column blocks per transform
     constexpr int ext_b = REAL ? (int) sizeof(R) : (int) sizeof(C);           // bytes per external time-domain element
     constexpr long long full_row_b = (long long) L * sizeof(C);
     constexpr int out_bins = REAL ? L + 1 : L;
     if (!inverse) {
         DSC_LAUNCH((two_pass_rows_kernel<R, B1, false>), grid, dim3(512), rl, stream, (const C *) in, (C *) work, (const C *) tw_full, (R) 1,
                            in_pitch * ext_b, (int) (in_len * ext_b));
-        DSC_LAUNCH((two_pass_cols_kernel<R, B1, false, REAL>), grid, dim3(512), cl, stream, (const C *) work, (C *) out, (const C *) tw_full,
+        DSC_LAUNCH((two_pass_cols_kernel<R, B1, false, REAL>), cgrid, dim3(CT), cl, stream, (const C *) work, (C *) out, (const C *) tw_full,
                            (const C *) tw_real, (long long) out_bins, out_bins);
     } else {
-        DSC_LAUNCH((two_pass_cols_kernel<R, B1, true, REAL>), grid, dim3(512), cl, stream, (const C *) in, (C *) work, (const C *) tw_full,
+        DSC_LAUNCH((two_pass_cols_kernel<R, B1, true, REAL>), cgrid, dim3(CT), cl, stream, (const C *) in, (C *) work, (const C *) tw_full,
                            (const C *) tw_real, in_pitch, in_len);
         DSC_LAUNCH((two_pass_rows_kernel<R, B1, true>), grid, dim3(512), rl, stream, (const C *) work, (C *) out, (const C *) tw_full,
                            (R) (1.0 / (double) L), full_row_b, (int) full_row_b);                 // 2/(2n) (dsc_fft.h:232) = 1/n (:168-175)
