@@ -293,8 +293,8 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
     }
 
     // register-resident 32768-point complex transform (c32 rows)
-    if (sp && j.mode == DSC_MODE_C2C && j.L == 32768 && inner == 1 && plan->tw_aux != nullptr) {
-        dsc_launch_fft32k_c32(j.x->data, j.out->data, (int) n_lines, j.x->shape[j.slot], j.in_len, j.inverse, plan->tw_aux, ctx->n_cu,
+    if (sp && (j.mode == DSC_MODE_C2C || j.mode == DSC_MODE_R2C_CAST) && j.L == 32768 && inner == 1 && plan->tw_aux != nullptr) {
+        dsc_launch_fft32k_c32(j.x->data, j.out->data, (int) n_lines, j.x->shape[j.slot], j.in_len, j.inverse, j.mode == DSC_MODE_R2C_CAST, plan->tw_aux, ctx->n_cu,
                               ctx->stream);
         ctx->last_fft_path = "c2c_32k_regs";
         return;
@@ -319,8 +319,9 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
     // (fft_xcd_fused.hip)
     static const bool fused_off = getenv("DSC_NO_FUSED_L2") != nullptr;           // A/B aid
     const bool fused_cplx = !packed;
+    const bool fused_cast = j.mode == DSC_MODE_R2C_CAST;                           // dsc_fft / dsc_ifft of a real tensor: widened while loading
     const bool fused_fwd = fused_cplx ? !j.inverse : j.mode == DSC_MODE_R2C_PACKED;
-    if ((packed || j.mode == DSC_MODE_C2C) && inner == 1 && !fused_off && dsc_fft_fused_l2_supports(j.L, sp, packed, !fused_fwd) &&
+    if ((packed || j.mode == DSC_MODE_C2C || fused_cast) && inner == 1 && !fused_off && dsc_fft_fused_l2_supports(j.L, sp, packed, !fused_fwd) &&
         ctx->scratch.capacity() >= dsc_fft_fused_l2_scratch_bytes(j.L, sp) + DSC_DEVICE_ALIGN) {
         const bool cplx = fused_cplx, fwd = fused_fwd;
         ctx->scratch.reset();
@@ -329,7 +330,7 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
             DSC_KERNEL_CHECK(hipHostMalloc((void **) &ctx->async_error, sizeof(unsigned), hipHostMallocDefault));
             *ctx->async_error = 0;
         }
-        if (dsc_launch_fft_fused_l2(j.x->data, j.out->data, n_lines, j.L, packed, !fwd, sp, blk, ctx->async_error, plan->tw_full, plan->tw_real,
+        if (dsc_launch_fft_fused_l2(j.x->data, j.out->data, n_lines, j.L, packed, !fwd, fused_cast, sp, blk, ctx->async_error, plan->tw_full, plan->tw_real,
                                     j.x->shape[j.slot], j.in_len, ctx->stream)) {
             ctx->last_fft_path = cplx ? "c2c_fused_l2" : fwd ? "r2c_fused_l2" : "c2r_fused_l2";
             return;
@@ -339,7 +340,8 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
     // long transforms of contiguous rows (config 5 = f64 N = 262144): two passes over HBM, rows kernel + column kernel with
     // the real pass fused (fft_r2c_2pass.hip)
     static const bool two_pass_off = getenv("DSC_NO_TWO_PASS") != nullptr;        // A/B aid (tools/bench_mid.py)
-    if ((packed || j.mode == DSC_MODE_C2C) && inner == 1 && !two_pass_off && dsc_fft_two_pass_supports(j.L, sp)) {
+    const bool two_pass_cast = j.mode == DSC_MODE_R2C_CAST && j.L == 262144;        // dsc_fft / dsc_ifft of a real tensor (that length only)
+    if ((packed || j.mode == DSC_MODE_C2C || two_pass_cast) && inner == 1 && !two_pass_off && dsc_fft_two_pass_supports(j.L, sp)) {
         const int L = j.L;
         const bool cplx = !packed;                                        // dsc_fft / dsc_ifft of a complex tensor
         const bool fwd = cplx ? !j.inverse : j.mode == DSC_MODE_R2C_PACKED, inv = !fwd;   // any row length: padded / cropped by the row descriptors
@@ -347,8 +349,9 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
         {
             const size_t csz = sp ? 8 : 16;
             const size_t row_bytes = (size_t) L * csz;
-            const size_t real_row = cplx ? (size_t) (fwd ? x_n : L) * csz : (size_t) (fwd ? x_n : 2 * L) * (csz / 2);       // time-domain side
-            const size_t bins_row = cplx ? (size_t) (fwd ? L : x_n) * csz : (size_t) (fwd ? L + 1 : x_n) * csz;               // frequency-domain side
+            const size_t in_el = two_pass_cast ? csz / 2 : csz;                   // bytes per input element of a complex transform
+            const size_t real_row = cplx ? (fwd ? (size_t) x_n * in_el : (size_t) L * csz) : (size_t) (fwd ? x_n : 2 * L) * (csz / 2);       // time-domain side
+            const size_t bins_row = cplx ? (fwd ? (size_t) L * csz : (size_t) x_n * in_el) : (size_t) (fwd ? L + 1 : x_n) * csz;               // frequency-domain side
             ctx->scratch.reset();
             long long chunk = (long long) ((ctx->scratch.capacity() - DSC_DEVICE_ALIGN) / row_bytes);
             if (chunk < 1) DSC_LOG_FATAL("scratch arena too small: a %d-point transform needs %.1f MB of scratch per row", 2 * L, row_bytes / 1048576.);
@@ -369,7 +372,7 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
                 const char *src = (const char *) j.x->data + (size_t) q * (fwd ? real_row : bins_row);
                 char *dst = (char *) j.out->data + (size_t) q * (fwd ? bins_row : real_row);
                 if (cplx)
-                    dsc_launch_fft_two_pass(src, dst, nl, L, inv, sp, work, plan->tw_full, x_n, j.in_len, ctx->stream);
+                    dsc_launch_fft_two_pass(src, dst, nl, L, inv, two_pass_cast, sp, work, plan->tw_full, x_n, j.in_len, ctx->stream);
                 else
                     dsc_launch_rfft_two_pass(src, dst, nl, L, inv, sp, work, plan->tw_full, plan->tw_real, x_n, j.in_len, ctx->stream);
             }

@@ -76,7 +76,8 @@ __device__ __forceinline__ void four_step_twiddle(cpx<R> (&v)[32], const cpx<R> 
 // rows kernel.  Forward (INV = false): z (row of packed reals) -> work[j1][k2].  Inverse: work -> z * scale.
 //   "writer" lanes  tid = 16 t + q : line j1 = 16 a + q, holds index 32 j2' + t  (pieces of 16 elements across q)
 //   "reader" lanes  tid = 32 q + tau: line j1 = 16 a + q, holds index tau + 32 k3 (pieces of 32 elements across tau)
-template<typename R, int B1, bool INV>
+// CAST (forward): the external rows hold REAL samples, widened on the way in (dsc_fft of a real tensor, dsc.cpp:1984-1988)
+template<typename R, int B1, bool INV, bool CAST = false>
 __global__ __launch_bounds__(512, (waves_per_eu<R>())) void two_pass_rows_kernel(const cpx<R> *__restrict__ in, cpx<R> *__restrict__ out,
                                                                               const cpx<R> *__restrict__ twL, R scale, long long ext_pitch_b,
                                                                               int ext_len_b) {
@@ -97,15 +98,16 @@ __global__ __launch_bounds__(512, (waves_per_eu<R>())) void two_pass_rows_kernel
                                             : __builtin_amdgcn_make_buffer_rsrc((void *) (out + row * L), 0, L * CB, 0x00020000);
     const int wq = tid & 15, wt = tid >> 4;              // writer mapping
     const int rq = tid >> 5, rtau = tid & 31;            // reader mapping
-    const int zoff = ((16 * a + wq) + L1 * wt) * CB;     // z[j1 + L1 (32 j2' + t)]: + j2' * 32 L1 elements
+    constexpr int EB = CAST ? (int) sizeof(R) : CB;      // bytes per external sample
+    const int zoff = ((16 * a + wq) + L1 * wt) * EB;     // z[j1 + L1 (32 j2' + t)]: + j2' * 32 L1 elements
     const int aoff = ((16 * a + rq) * 1024 + rtau) * CB; // A[j1][tau + 32 k3]:      + k3 * 32 elements
     const int j1r = 16 * a + rq;
-    constexpr int ZSTEP = 32 * L1 * CB, ASTEP = 32 * CB;
+    constexpr int ZSTEP = 32 * L1 * EB, ASTEP = 32 * CB;
 
     C u[32], v[32];
     if constexpr (!INV) {
 #pragma unroll
-        for (int m = 0; m < 32; ++m) u[m] = buf_load<kStream>(rin, zoff, m * ZSTEP, R{});
+        for (int m = 0; m < 32; ++m) u[m] = CAST ? buf_load_real<kStream>(rin, zoff, m * ZSTEP, R{}) : buf_load<kStream>(rin, zoff, m * ZSTEP, R{});
         __syncthreads();
         dft_n<R, false, 32>(u);                                               // over j2' -> k2' in u[brev(k2')]
 #pragma unroll
@@ -184,7 +186,8 @@ struct stage_ptrs {
 //   lanes tid = NC t + ell: local column ell (S side 0..H-1, mirror side H..NC-1), slice t of the L1-point axis (j1 = B1 i + t)
 //   element e = B1 i' + p of a thread after the transform: k1 = t + B1 i' + 32 k3, k3 = brev(p)
 //   REAL = false: plain complex transform (dsc_fft / dsc_ifft): columns NC b + ell, no pairing, rows of L bins
-template<typename R, int B1, bool INV, bool REAL>
+// CAST (inverse complex): the bins rows hold REAL values (dsc_ifft of a real tensor)
+template<typename R, int B1, bool INV, bool REAL, bool CAST = false>
 __global__ __launch_bounds__((cols_threads<R, B1>()), (waves_per_eu<R>())) void two_pass_cols_kernel(const cpx<R> *__restrict__ in, cpx<R> *__restrict__ out,
                                                                               const cpx<R> *__restrict__ twL, const cpx<R> *__restrict__ tw_real,
                                                                               long long bins_pitch, int bins_len) {
@@ -207,9 +210,10 @@ __global__ __launch_bounds__((cols_threads<R, B1>()), (waves_per_eu<R>())) void 
     const int ellp = (last && (ell == H - 1 || ell == H)) ? ell : NC - 1 - ell;   // local column of the pairing partner
     const C *work = INV ? out + row * L : in + row * L;
     // bins_pitch / bins_len (in bins): the inverse reads rows of any length, missing bins as zero (dsc.cpp:2149-2157)
-    const C *bins = INV ? in + row * bins_pitch : out + row * bins_pitch;
+    constexpr int BB = CAST ? (int) sizeof(R) : CB;                           // bytes per external bin
+    const C *bins = INV ? (const C *) ((const char *) in + row * bins_pitch * BB) : out + row * bins_pitch;
     const __amdgpu_buffer_rsrc_t rwork = __builtin_amdgcn_make_buffer_rsrc((void *) work, 0, L * CB, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rbins = __builtin_amdgcn_make_buffer_rsrc((void *) bins, 0, bins_len * CB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbins = __builtin_amdgcn_make_buffer_rsrc((void *) bins, 0, bins_len * BB, 0x00020000);
     const int woff = (t * 1024 + col) * CB;
     const int boff = col * CB;
     constexpr int kBinsLoad = REAL ? kBinsLoadReal : kStream;
@@ -290,7 +294,9 @@ __global__ __launch_bounds__((cols_threads<R, B1>()), (waves_per_eu<R>())) void 
     } else {
         // ---- load the bins in the layout the forward kernel leaves them in (natural k3 order), pre-pass (dsc_fft.h:194-228)
 #pragma unroll
-        for (int e = 0; e < 32; ++e) v[e] = buf_load<kBinsLoad>(rbins, boff, (t + B1 * (e / B1) + 32 * (e % B1)) * BSTEP, R{});
+        for (int e = 0; e < 32; ++e)
+            v[e] = CAST ? buf_load_real<kStream>(rbins, col * BB, (t + B1 * (e / B1) + 32 * (e % B1)) * 1024 * BB, R{})
+                        : buf_load<kBinsLoad>(rbins, boff, (t + B1 * (e / B1) + 32 * (e % B1)) * BSTEP, R{});
         C ylast = C{(R) 0, (R) 0};
         if (col0 && t == 0) { ylast = buf_load<kBinsLoad>(rbins, L * CB, 0, R{}); v[0].y = (R) 0; }      // real parts only at k = 0 and k = L
         __syncthreads();
@@ -358,7 +364,7 @@ __global__ __launch_bounds__((cols_threads<R, B1>()), (waves_per_eu<R>())) void 
 
 // in_pitch / in_len: pitch and valid length of the INPUT rows in input elements (REAL: reals forward, bins inverse; complex
 // transforms: complex samples both ways)
-template<typename R, int B1, bool REAL>
+template<typename R, int B1, bool REAL, bool CAST = false>
 void launch_pair(const void *in, void *out, long long rows, void *work, const void *tw_full, const void *tw_real, bool inverse,
                  long long in_pitch, int in_len, hipStream_t stream) {
     using C = cpx<R>;
@@ -366,24 +372,24 @@ void launch_pair(const void *in, void *out, long long rows, void *work, const vo
     constexpr int rl = rows_lds_bytes<R>(), cl = cols_lds_bytes<R, B1>();
     static unsigned long long attr_devices = 0;
     if (dsc_first_use_on_device(attr_devices)) {
-        DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) two_pass_rows_kernel<R, B1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, rl));
+        DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) two_pass_rows_kernel<R, B1, false, CAST>, hipFuncAttributeMaxDynamicSharedMemorySize, rl));
         DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) two_pass_rows_kernel<R, B1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, rl));
         DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) two_pass_cols_kernel<R, B1, false, REAL>, hipFuncAttributeMaxDynamicSharedMemorySize, cl));
-        DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) two_pass_cols_kernel<R, B1, true, REAL>, hipFuncAttributeMaxDynamicSharedMemorySize, cl));
+        DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) two_pass_cols_kernel<R, B1, true, REAL, CAST>, hipFuncAttributeMaxDynamicSharedMemorySize, cl));
     }
     const dim3 grid((unsigned) (rows * 2 * B1));          // L1 / 16 row groups per transform
     constexpr int CT = cols_threads<R, B1>();
     const dim3 cgrid((unsigned) (rows * (1024 / (CT / B1))));   // 1024 / NC column blocks per transform
-    constexpr int ext_b = REAL ? (int) sizeof(R) : (int) sizeof(C);           // bytes per external time-domain element
+    constexpr int ext_b = (REAL || CAST) ? (int) sizeof(R) : (int) sizeof(C);  // bytes per external time-domain element
     constexpr long long full_row_b = (long long) L * sizeof(C);
     constexpr int out_bins = REAL ? L + 1 : L;
     if (!inverse) {
-        DSC_LAUNCH((two_pass_rows_kernel<R, B1, false>), grid, dim3(512), rl, stream, (const C *) in, (C *) work, (const C *) tw_full, (R) 1,
+        DSC_LAUNCH((two_pass_rows_kernel<R, B1, false, CAST>), grid, dim3(512), rl, stream, (const C *) in, (C *) work, (const C *) tw_full, (R) 1,
                            in_pitch * ext_b, (int) (in_len * ext_b));
         DSC_LAUNCH((two_pass_cols_kernel<R, B1, false, REAL>), cgrid, dim3(CT), cl, stream, (const C *) work, (C *) out, (const C *) tw_full,
                            (const C *) tw_real, (long long) out_bins, out_bins);
     } else {
-        DSC_LAUNCH((two_pass_cols_kernel<R, B1, true, REAL>), cgrid, dim3(CT), cl, stream, (const C *) in, (C *) work, (const C *) tw_full,
+        DSC_LAUNCH((two_pass_cols_kernel<R, B1, true, REAL, CAST>), cgrid, dim3(CT), cl, stream, (const C *) in, (C *) work, (const C *) tw_full,
                            (const C *) tw_real, in_pitch, in_len);
         DSC_LAUNCH((two_pass_rows_kernel<R, B1, true>), grid, dim3(512), rl, stream, (const C *) work, (C *) out, (const C *) tw_full,
                            (R) (1.0 / (double) L), full_row_b, (int) full_row_b);                 // 2/(2n) (dsc_fft.h:232) = 1/n (:168-175)
@@ -391,13 +397,15 @@ void launch_pair(const void *in, void *out, long long rows, void *work, const vo
 }
 
 template<typename R, bool REAL>
-void launch_len(int L, const void *in, void *out, long long rows, void *work, const void *tw_full, const void *tw_real, bool inverse,
+void launch_len(int L, bool cast, const void *in, void *out, long long rows, void *work, const void *tw_full, const void *tw_real, bool inverse,
                 long long in_pitch, int in_len, hipStream_t stream) {
     switch (L) {
         case 32768:  launch_pair<R, 1, REAL>(in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream); break;
         case 65536:  launch_pair<R, 2, REAL>(in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream); break;
         case 131072: launch_pair<R, 4, REAL>(in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream); break;
-        default:     launch_pair<R, 8, REAL>(in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream); break;
+        default:
+            if constexpr (!REAL) { if (cast) { launch_pair<R, 8, false, true>(in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream); break; } }
+            launch_pair<R, 8, REAL>(in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream); break;
     }
 }
 
@@ -414,14 +422,15 @@ bool dsc_fft_two_pass_supports(int L, bool single_precision) {
 void dsc_launch_rfft_two_pass(const void *in, void *out, long long rows, int L, bool inverse, bool single_precision, void *work,
                               const void *tw_full, const void *tw_real, long long in_pitch, int in_len, hipStream_t stream) {
     if (rows <= 0) return;
-    if (single_precision) launch_len<float, true>(L, in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream);
-    else                  launch_len<double, true>(L, in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream);
+    if (single_precision) launch_len<float, true>(L, false, in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream);
+    else                  launch_len<double, true>(L, false, in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream);
 }
 
 // complex transforms of the same lengths: in = [rows][in_pitch] complex of which in_len <= L are transformed, out = [rows][L]
-void dsc_launch_fft_two_pass(const void *in, void *out, long long rows, int L, bool inverse, bool single_precision, void *work,
+// cast (L = 262144 only): the input rows hold REAL values (dsc_fft / dsc_ifft of a real tensor); in_pitch / in_len count reals
+void dsc_launch_fft_two_pass(const void *in, void *out, long long rows, int L, bool inverse, bool cast, bool single_precision, void *work,
                              const void *tw_full, long long in_pitch, int in_len, hipStream_t stream) {
     if (rows <= 0) return;
-    if (single_precision) launch_len<float, false>(L, in, out, rows, work, tw_full, tw_full, inverse, in_pitch, in_len, stream);
-    else                  launch_len<double, false>(L, in, out, rows, work, tw_full, tw_full, inverse, in_pitch, in_len, stream);
+    if (single_precision) launch_len<float, false>(L, cast, in, out, rows, work, tw_full, tw_full, inverse, in_pitch, in_len, stream);
+    else                  launch_len<double, false>(L, cast, in, out, rows, work, tw_full, tw_full, inverse, in_pitch, in_len, stream);
 }

@@ -150,7 +150,9 @@ __device__ __forceinline__ void four_step_twiddle16(cpx<R> (&v)[16], const cpx<R
 // L2 = 128, 256 or 512: the row-task transform length (L = 256 L2).  kNT = 256 threads (tasks of 4096 complex, 16 columns) or 512
 // (8192 complex, 32 columns: f32 rows of 131072 points, whose pieces would be 64 B otherwise); TS = L2 / (kNT / 16) workgroups
 // per team.
-template<typename R, bool REAL, bool INV, int L2, int kNT>
+// CAST (complex transforms only): the input rows are REAL and widened on the way in (dsc_fft / dsc_ifft of a real tensor,
+// dsc.cpp:1984-1988).
+template<typename R, bool REAL, bool INV, int L2, int kNT, bool CAST = false>
 __global__ __launch_bounds__(kNT, (kNT == 512 ? 4 : 2)) void fused_l2_kernel(const char *__restrict__ ext, char *__restrict__ ext_out,
                                                                                const cpx<R> *__restrict__ bins_in, cpx<R> *__restrict__ bins_out,
                                                                                cpx<R> *scratch, fused_ctl *ctl, unsigned *host_error, int rows, int teams_cap,
@@ -266,12 +268,13 @@ __global__ __launch_bounds__(kNT, (kNT == 512 ? 4 : 2)) void fused_l2_kernel(con
     //   tau = ka + 16 c, holds A[j1][tau + 32 kb] (the 32-point second stage = a radix-2 step folded into the LDS read + 16 points)
     const int wq = tid % LINES, ws = tid / LINES;
     const int rq = tid / TPL, rtau = tid % TPL;
-    const int zoff = ((LINES * rank + wq) + 256 * ws) * CB;    // REAL: z[j] = (x[2j], x[2j + 1])
+    constexpr int EB = (CAST && !INV) ? (int) sizeof(R) : CB;      // bytes per sample on the time-domain side
+    const int zoff = ((LINES * rank + wq) + 256 * ws) * EB;    // REAL: z[j] = (x[2j], x[2j + 1])
     const int aoff = ((LINES * rank + rq) * L2 + rtau) * CB;
     const int j1r = LINES * rank + rq;
     // the seven table values of the inter-pass twiddle are re-read per row (L2 hits) instead of living in 14 / 28 registers
     auto opaque_j1 = [&]() { int j = j1r; asm volatile("" : "+v"(j)); return j; };
-    constexpr int ZSTEP = TPL * 256 * CB, ASTEP = TPL * CB;
+    constexpr int ZSTEP = TPL * 256 * EB, ASTEP = TPL * CB;
     // column task `rank`: lanes tid = 16 t + ell: column ell (REAL: 8 columns 8 b + 1 .. 8 b + 8 and their mirrors; column 0
     // takes the place of the duplicate 128 in the last block), slice t of the 256-point axis (j1 = t + 16 i; k1 = t + 16 k)
     const int ell = tid % NC, t = tid / NC;
@@ -292,8 +295,15 @@ __global__ __launch_bounds__(kNT, (kNT == 512 ? 4 : 2)) void fused_l2_kernel(con
         if constexpr (!INV) {
             const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *) (ext + (size_t) row * ext_pitch_b), 0, ext_len_b, 0x00020000);
 #pragma unroll
-            for (int m = 0; m < 16; ++m) dst[m] = buf_load<DSC_FUSED_EXT_LOAD>(r, zoff, m * ZSTEP, R{});
+            for (int m = 0; m < 16; ++m) dst[m] = CAST ? buf_load_real<DSC_FUSED_EXT_LOAD>(r, zoff, m * ZSTEP, R{}) : buf_load<DSC_FUSED_EXT_LOAD>(r, zoff, m * ZSTEP, R{});
         } else {
+            if constexpr (CAST) {                                   // dsc_ifft of a real tensor: rows of reals
+                constexpr int RB = (int) sizeof(R);
+                const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *) ((const char *) bins_in + (size_t) row * bins_pitch * RB), 0, bins_len * RB, 0x00020000);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) dst[e] = buf_load_real<kStream>(r, (L2 * t + col) * RB, 16 * e * L2 * RB, R{});
+                return;
+            }
             const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *) (bins_in + (size_t) row * bins_pitch), 0, bins_len * CB, 0x00020000);
 #pragma unroll
             for (int e = 0; e < 16; ++e) dst[e] = buf_load<BL>(r, boff, 16 * e * BSTEP, R{});
@@ -660,7 +670,7 @@ constexpr int teams_cap_of(int L, bool single_precision) {
     return wg_per_cu(L, single_precision) * 32 / team_size_of(L, single_precision) + 1;       // workgroups per XCD (32 CUs) / team size
 }
 
-template<typename R, bool REAL, bool INV, int L2, int NT>
+template<typename R, bool REAL, bool INV, int L2, int NT, bool CAST = false>
 bool launch_one(const void *in, void *out, long long rows, void *scratch, unsigned *host_error, const void *tw_full, const void *tw_real, double scale,
                 long long ext_pitch_b, int ext_len_b, long long bins_pitch, int bins_len, hipStream_t stream) {
     using C = cpx<R>;
@@ -673,7 +683,7 @@ bool launch_one(const void *in, void *out, long long rows, void *scratch, unsign
     if (dev < 0 || dev >= 64) return false;
     if (grids[dev] == 0) {
         int per_cu = 0, cus = 0;
-        DSC_KERNEL_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *) fused_l2_kernel<R, REAL, INV, L2, NT>, NT, 0));
+        DSC_KERNEL_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *) fused_l2_kernel<R, REAL, INV, L2, NT, CAST>, NT, 0));
         DSC_KERNEL_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         if (per_cu > wg_per_cu(L, sizeof(R) == 4)) per_cu = wg_per_cu(L, sizeof(R) == 4);
         int g = cus * per_cu;
@@ -685,7 +695,7 @@ bool launch_one(const void *in, void *out, long long rows, void *scratch, unsign
     fused_ctl *ctl = (fused_ctl *) scratch;
     C *rowsbuf = (C *) ((char *) scratch + dsc_fft_fused_l2_ctl_bytes());
     DSC_KERNEL_CHECK(hipMemsetAsync(ctl, 0, sizeof(fused_ctl), stream));
-    DSC_LAUNCH((fused_l2_kernel<R, REAL, INV, L2, NT>), dim3((unsigned) grids[dev]), dim3(NT), 0, stream, INV ? (const char *) nullptr : (const char *) in,
+    DSC_LAUNCH((fused_l2_kernel<R, REAL, INV, L2, NT, CAST>), dim3((unsigned) grids[dev]), dim3(NT), 0, stream, INV ? (const char *) nullptr : (const char *) in,
                INV ? (char *) out : (char *) nullptr, INV ? (const C *) in : (const C *) nullptr, INV ? (C *) nullptr : (C *) out, rowsbuf, ctl, host_error, (int) rows,
                cap, (const C *) tw_full, (const C *) tw_real, (R) scale, ext_pitch_b, ext_len_b, bins_pitch, bins_len);
     return true;
@@ -711,7 +721,7 @@ size_t dsc_fft_fused_l2_scratch_bytes(int L, bool single_precision) {
 }
 
 template<typename R, int L2, int NT = 256>
-static bool launch_any(const void *in, void *out, long long rows, bool real, bool inverse, void *scratch, unsigned *host_error, const void *tw_full,
+static bool launch_any(const void *in, void *out, long long rows, bool real, bool inverse, bool cast, void *scratch, unsigned *host_error, const void *tw_full,
                        const void *tw_real, long long in_pitch, int in_len, hipStream_t stream) {
     constexpr long long CBl = 2 * sizeof(R);
     constexpr int L = 256 * L2;
@@ -721,19 +731,23 @@ static bool launch_any(const void *in, void *out, long long rows, bool real, boo
                                                             (long long) L + 1, L + 1, stream);
         return launch_one<R, true, true, L2, NT>(in, out, rows, scratch, host_error, tw_full, tw_real, inv_scale, (long long) L * CBl, (int) (L * CBl), in_pitch, in_len, stream);
     }
+    if (inverse && cast) return launch_one<R, false, true, L2, NT, true>(in, out, rows, scratch, host_error, tw_full, tw_full, inv_scale, (long long) L * CBl, (int) (L * CBl), in_pitch, in_len, stream);
+    if (!inverse && cast) return launch_one<R, false, false, L2, NT, true>(in, out, rows, scratch, host_error, tw_full, tw_full, 1.0, in_pitch * (long long) sizeof(R),
+                                                                       (int) (in_len * sizeof(R)), (long long) L, L, stream);
     if (!inverse) return launch_one<R, false, false, L2, NT>(in, out, rows, scratch, host_error, tw_full, tw_full, 1.0, in_pitch * CBl, (int) (in_len * CBl), (long long) L, L, stream);
     return launch_one<R, false, true, L2, NT>(in, out, rows, scratch, host_error, tw_full, tw_full, inv_scale, (long long) L * CBl, (int) (L * CBl), in_pitch, in_len, stream);
 }
 
-// Same arguments as dsc_launch_rfft_two_pass / dsc_launch_fft_two_pass (real = packed-real transform).  Returns false when the
+// Same arguments as dsc_launch_rfft_two_pass / dsc_launch_fft_two_pass (real = packed-real transform; cast = forward complex
+// transform of REAL samples: in_pitch / in_len then count reals).  Returns false when the
 // launch cannot be made fully resident on this device (the caller falls back to the two-kernel route).
-bool dsc_launch_fft_fused_l2(const void *in, void *out, long long rows, int L, bool real, bool inverse, bool single_precision, void *scratch,
+bool dsc_launch_fft_fused_l2(const void *in, void *out, long long rows, int L, bool real, bool inverse, bool cast, bool single_precision, void *scratch,
                              unsigned *host_error, const void *tw_full, const void *tw_real, long long in_pitch, int in_len, hipStream_t stream) {
     if (rows <= 0) return true;
     if (!dsc_fft_fused_l2_supports(L, single_precision, real, inverse) || rows > 0x7fffff00) return false;
-    if (L == 131072 && single_precision) return launch_any<float, 512, 512>(in, out, rows, real, inverse, scratch, host_error, tw_full, tw_real, in_pitch, in_len, stream);
-    if (L == 131072) return launch_any<double, 512>(in, out, rows, real, inverse, scratch, host_error, tw_full, tw_real, in_pitch, in_len, stream);
-    if (L == 32768) return launch_any<double, 128>(in, out, rows, real, inverse, scratch, host_error, tw_full, tw_real, in_pitch, in_len, stream);
-    return single_precision ? launch_any<float, 256, 512>(in, out, rows, real, inverse, scratch, host_error, tw_full, tw_real, in_pitch, in_len, stream)
-                            : launch_any<double, 256>(in, out, rows, real, inverse, scratch, host_error, tw_full, tw_real, in_pitch, in_len, stream);
+    if (L == 131072 && single_precision) return launch_any<float, 512, 512>(in, out, rows, real, inverse, cast, scratch, host_error, tw_full, tw_real, in_pitch, in_len, stream);
+    if (L == 131072) return launch_any<double, 512>(in, out, rows, real, inverse, cast, scratch, host_error, tw_full, tw_real, in_pitch, in_len, stream);
+    if (L == 32768) return launch_any<double, 128>(in, out, rows, real, inverse, cast, scratch, host_error, tw_full, tw_real, in_pitch, in_len, stream);
+    return single_precision ? launch_any<float, 256, 512>(in, out, rows, real, inverse, cast, scratch, host_error, tw_full, tw_real, in_pitch, in_len, stream)
+                            : launch_any<double, 256>(in, out, rows, real, inverse, cast, scratch, host_error, tw_full, tw_real, in_pitch, in_len, stream);
 }

@@ -101,7 +101,7 @@ void   dsc_r2c64k_build_tables(void *host_dst);          // fills a host staging
 void   dsc_launch_rfft64k(const float *x, void *X, int batch, int in_pitch, int in_len, const void *aux, int n_cu, hipStream_t stream);
 void   dsc_launch_irfft64k(const void *X, float *x, int batch, int in_pitch, int in_len, const void *aux, int n_cu, hipStream_t stream);   // pitch / valid length in bins
 // complex 32768-point transform of c32 rows in the same design (z: [batch][in_pitch], in_len <= 32768 samples used)
-void   dsc_launch_fft32k_c32(const void *z, void *Z, int batch, int in_pitch, int in_len, bool inverse, const void *aux, int n_cu,
+void   dsc_launch_fft32k_c32(const void *z, void *Z, int batch, int in_pitch, int in_len, bool inverse, bool cast, const void *aux, int n_cu,
                              hipStream_t stream);
 // y = irfft(rfft(s) * H) fused; H: [32769] c32
 void   dsc_launch_filter64k(const float *s, const void *H, float *y, int batch, int in_pitch, int in_len, const void *aux, int n_cu,
@@ -117,7 +117,7 @@ void   dsc_launch_fft_regs_cols(const void *in, void *out, long long slices, int
 // work: rows * L complex of scratch; tw_full: W_L^k, k < L; tw_real: W_{2L}^k, k <= L (the REAL plan's own tables).
 bool   dsc_fft_two_pass_supports(int L, bool single_precision);
 // the same lengths for complex data (dsc_fft / dsc_ifft of complex tensors): in = complex rows, out = [rows][L]
-void   dsc_launch_fft_two_pass(const void *in, void *out, long long rows, int L, bool inverse, bool single_precision, void *work,
+void   dsc_launch_fft_two_pass(const void *in, void *out, long long rows, int L, bool inverse, bool cast, bool single_precision, void *work,
                                const void *tw_full, long long in_pitch, int in_len, hipStream_t stream);
 // in_pitch / in_len: pitch and valid length of the input rows in input elements (reals forward, bins inverse): shorter rows are zero
 // padded, longer ones cropped.
@@ -131,7 +131,7 @@ void   dsc_launch_rfft_two_pass(const void *in, void *out, long long rows, int L
 bool   dsc_fft_fused_l2_supports(int L, bool single_precision, bool real, bool inverse);
 size_t dsc_fft_fused_l2_ctl_bytes();
 size_t dsc_fft_fused_l2_scratch_bytes(int L, bool single_precision);
-bool   dsc_launch_fft_fused_l2(const void *in, void *out, long long rows, int L, bool real, bool inverse, bool single_precision, void *scratch,
+bool   dsc_launch_fft_fused_l2(const void *in, void *out, long long rows, int L, bool real, bool inverse, bool cast, bool single_precision, void *scratch,
                                unsigned *host_error, const void *tw_full, const void *tw_real, long long in_pitch, int in_len, hipStream_t stream);
 
 // ---- register-resident transforms of contiguous full lines, complex length 256 .. 16384 (f32, f64; f32 C2C also 32768)

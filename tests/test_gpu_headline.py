@@ -545,6 +545,26 @@ def test_fused_l2_paired_teams_every_element(dsc):
     dsc.synchronize()
 
 
+@pytest.mark.parametrize('dt,L,path', [(np.float32, 32768, 'c2c_32k_regs'), (np.float32, 65536, 'c2c_fused_l2'), (np.float32, 131072, 'c2c_fused_l2'),
+                                       (np.float32, 262144, 'c2c_2pass_regs'), (np.float64, 32768, 'c2c_fused_l2'), (np.float64, 131072, 'c2c_fused_l2'),
+                                       (np.float64, 262144, 'c2c_2pass_regs')])
+def test_fft_and_ifft_of_real_tensors_on_the_long_row_kernels(dsc, dt, L, path):
+    """dsc_fft / dsc_ifft of a REAL tensor cast while gathering (dsc.cpp:1984-1988): on the long-row kernels the samples are widened
+    on the way in (before round 2 these lengths fell to the generic four-step path at 7-9 % of the roofline).  Full, zero-padded
+    and cropped rows against the oracle."""
+    from oracle import port
+    rng = np.random.default_rng(L + 3)
+    rows = 3 if L >= 262144 else 9
+    for ls in (L, L - 300, L + 40):
+        x = rng.standard_normal((rows, ls)).astype(dt)
+        F = dsc.fft(dsc.from_numpy(x), n=L)
+        assert dsc.last_fft_path() == path, (dsc.last_fft_path(), path)
+        assert_close(F.numpy(), port.fft(x, L), what=f'fft(real) {np.dtype(dt).name} L={L} ls={ls}')
+        G = dsc.ifft(dsc.from_numpy(x), n=L)
+        assert dsc.last_fft_path() == path
+        assert_close(G.numpy(), port.ifft(x, L), what=f'ifft(real) {np.dtype(dt).name} L={L} ls={ls}')
+
+
 def test_fused_l2_f32_every_element(dsc):
     """The f32 form of the team kernel (512-thread tasks; 65536- and 131072-point rows), every element of every row, repeatedly:
     the test that exposed a missing LDS barrier between rows (a wave starting the next row's exchange while another still read
