@@ -1,5 +1,5 @@
 // fft_r2c_2pass.hip — long real FFTs in TWO passes over HBM: packed complex length L = L1 x 1024 with
-// L1 = 32 B1 in {32, 64, 128, 256}, i.e. real lengths 65536 (f64 only; f32 has fft_r2c_64k.hip), 131072, 262144
+// L1 = 32 B1 in {32, 64, 128, 256, 512, 1024}, i.e. real lengths 65536 (f64 only; f32 has fft_r2c_64k.hip), 131072, 262144
 // (BASELINE config 5 in f64) and 524288, f32 and f64.  A row is too big for one CU, so (four-step, DIT):
 //
 //   j = j1 + L1 j2   (input),      k = 1024 k1 + k2   (output),      j1, k1 < L1,  j2, k2 < 1024
@@ -48,7 +48,7 @@ constexpr int kPQ = 1060;                    // rows kernel: plane pitch per lin
 template<typename R> constexpr int rows_lds_bytes() { return (16 * kPQ + 2 * 1024) * (int) sizeof(R); }          // plane + W_1024
 // threads of the column kernel: 512, or 1024 for f32 with L1 = 256 (N = 524288) — with 512 its runs are 32 columns = 256 B,
 // skewed on the spectrum side (measured 1.33 ms for that kernel against 0.78 ms for the rows kernel of the same transform)
-template<typename R, int B1> constexpr int cols_threads() { return (sizeof(R) == 4 && B1 == 8) ? 1024 : 512; }
+template<typename R, int B1> constexpr int cols_threads() { return (sizeof(R) == 4 && B1 >= 8) ? 1024 : 512; }
 template<typename R, int B1> constexpr int cols_lds_bytes() { return (32 * cols_threads<R, B1>() + 2 * 32 * B1 + cols_threads<R, B1>()) * (int) sizeof(R); }  // plane + W_L1 + slack: the unused partner read of bin 0 lands one row past the plane
 template<typename R> constexpr int waves_per_eu() { return sizeof(R) == 8 ? 2 : 4; }     // f32: <= 128 VGPRs, two workgroups per CU
 
@@ -200,7 +200,7 @@ __global__ __launch_bounds__((cols_threads<R, B1>()), (waves_per_eu<R>())) void 
     R *plane = (R *) lds_raw;
     C *wl1 = (C *) (plane + 32 * cols_threads<R, B1>());
     const int tid = threadIdx.x;
-    if (tid < L1) wl1[tid] = twL[tid * 1024];                                 // W_L1^m = W_L^{1024 m}
+    for (int i = tid; i < L1; i += cols_threads<R, B1>()) wl1[i] = twL[i * 1024];      // W_L1^m = W_L^{1024 m}
     const long long row = blockIdx.x / BLOCKS;
     const int b = blockIdx.x % BLOCKS;
     const int ell = tid % NC, t = tid / NC;
@@ -403,6 +403,8 @@ void launch_len(int L, bool cast, const void *in, void *out, long long rows, voi
         case 32768:  launch_pair<R, 1, REAL>(in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream); break;
         case 65536:  launch_pair<R, 2, REAL>(in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream); break;
         case 131072: launch_pair<R, 4, REAL>(in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream); break;
+        case 524288: launch_pair<R, 16, REAL>(in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream); break;
+        case 1048576: launch_pair<R, 32, REAL>(in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream); break;
         default:
             if constexpr (!REAL) { if (cast) { launch_pair<R, 8, false, true>(in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream); break; } }
             launch_pair<R, 8, REAL>(in, out, rows, work, tw_full, tw_real, inverse, in_pitch, in_len, stream); break;
@@ -413,7 +415,7 @@ void launch_len(int L, bool cast, const void *in, void *out, long long rows, voi
 
 bool dsc_fft_two_pass_supports(int L, bool single_precision) {
     if (L == 32768) return !single_precision;             // f32: fft_r2c_64k.hip, one pass
-    return L == 65536 || L == 131072 || L == 262144;
+    return L == 65536 || L == 131072 || L == 262144 || L == 524288 || L == 1048576;
 }
 
 // forward: in = [rows][in_pitch] reals of which in_len <= 2L are transformed (the rest of the length is zero), out =

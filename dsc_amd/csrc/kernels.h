@@ -113,7 +113,7 @@ void   dsc_launch_fft_regs_cols(const void *in, void *out, long long slices, int
                                 const void *tw_full, const void *tw_real, double scale, int in_axis, int in_len, int out_axis, hipStream_t stream);
 
 // ---- long real transforms in two passes over HBM (fft_r2c_2pass.hip): packed complex length L = 32768 (f64 only),
-// 65536, 131072, 262144; f32 and f64.  forward: reals -> out = [rows][L + 1] bins; inverse: bins -> [rows][2L] reals.
+// 65536 ... 1048576; f32 and f64.  forward: reals -> out = [rows][L + 1] bins; inverse: bins -> [rows][2L] reals.
 // work: rows * L complex of scratch; tw_full: W_L^k, k < L; tw_real: W_{2L}^k, k <= L (the REAL plan's own tables).
 bool   dsc_fft_two_pass_supports(int L, bool single_precision);
 // the same lengths for complex data (dsc_fft / dsc_ifft of complex tensors): in = complex rows, out = [rows][L]

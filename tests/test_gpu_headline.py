@@ -38,7 +38,9 @@ def test_paths_are_the_hand_written_kernels(dsc):
     # anything the fast kernels do not cover must still be right through the generic path
     dsc.rfft(dsc.from_numpy(np.ones((65536, 2), np.float32)), axis=0)       # strided lines: transposed to the back first
     assert dsc.last_fft_path() == 'r2c_64k_regs'
-    dsc.rfft(dsc.from_numpy(np.ones((2, 1 << 21), np.float32)))             # beyond the two-pass kernels
+    dsc.rfft(dsc.from_numpy(np.ones((2, 1 << 21), np.float32)))             # the longest row of the two-kernel route
+    assert dsc.last_fft_path() == 'r2c_2pass_regs'
+    dsc.rfft(dsc.from_numpy(np.ones((1, 1 << 22), np.float32)))             # beyond it
     assert dsc.last_fft_path() == 'generic_4step'
     dsc.rfft(dsc.from_numpy(np.ones((256, 8), np.float32)), axis=0)         # strided lines of 32 .. 2048 complex points: the column kernel
     assert dsc.last_fft_path() == 'regs_cols'
@@ -355,8 +357,8 @@ def test_full_size_f64_config5(dsc):
     assert rel_l2(bh, x) <= 1e-14 and np.max(np.abs(bh - x)) < 1e-12
 
 
-@pytest.mark.parametrize('dt,n', [(np.float32, 131072), (np.float32, 262144), (np.float32, 524288),
-                                  (np.float64, 65536), (np.float64, 131072), (np.float64, 524288)])
+@pytest.mark.parametrize('dt,n', [(np.float32, 131072), (np.float32, 262144), (np.float32, 524288), (np.float32, 1048576), (np.float32, 2097152),
+                                  (np.float64, 65536), (np.float64, 131072), (np.float64, 524288), (np.float64, 1048576), (np.float64, 2097152)])
 def test_two_pass_long_transforms(dsc, dt, n):
     """Real lengths beyond one CU's registers (fft_r2c_2pass.hip: rows kernel + column kernel with the real pass fused),
     every L1 = n / 2048 in {32, 64, 128, 256}, f32 and f64 (f64 262144 = config 5 has its own tests)."""
@@ -608,7 +610,8 @@ def test_two_pass_padded_rows(dsc, dt, n):
         assert_close(b.numpy()[0], port.irfft(Y[0], bins), what=f'padded 2-pass irfft bins={bins} lb={lb}')
 
 
-@pytest.mark.parametrize('dt,L', [(np.complex64, 65536), (np.complex64, 262144), (np.complex128, 32768), (np.complex128, 131072)])
+@pytest.mark.parametrize('dt,L', [(np.complex64, 65536), (np.complex64, 262144), (np.complex64, 524288), (np.complex64, 1048576), (np.complex128, 32768),
+                                  (np.complex128, 131072), (np.complex128, 524288), (np.complex128, 1048576)])
 def test_two_pass_complex_transforms(dsc, dt, L):
     """dsc_fft / dsc_ifft of complex rows longer than one CU's registers: the two-pass kernels without the real pass,
     full and zero-padded rows."""
@@ -727,6 +730,16 @@ def test_fused_filter_mid_sizes(dsc, dt, n):
     assert np.abs(y - want).max() <= (2e-3 if dt == np.float32 else 1e-10)
 
 
+def test_generic_four_step_beyond_the_two_pass_lengths(dsc):
+    """Rows longer than the two-kernel route covers (complex length above 2^20) still go through the generic four-step path."""
+    rng = np.random.default_rng(22)
+    x = rng.standard_normal((1, 1 << 22)).astype(np.float32)
+    X = dsc.rfft(dsc.from_numpy(x))
+    assert dsc.last_fft_path() == 'generic_4step'
+    assert rel_l2(X.numpy(), np.fft.rfft(x.astype(np.float64), axis=-1)) <= 2e-6
+    assert rel_l2(dsc.irfft(X).numpy(), x) <= 2e-6
+
+
 @pytest.mark.parametrize('dt', [np.float32, np.float64])
 def test_every_power_of_two_length(dsc, dt):
     """One sweep over every transform length 2 .. 2^20, all four transforms, full and zero-padded rows,
@@ -753,10 +766,11 @@ def test_every_power_of_two_length(dsc, dt):
             zp = np.zeros((rows, n), np.complex128)
             zp[:, :ls] = z
             Z = dsc.fft(dsc.from_numpy(z), n=n)
+            paths.setdefault(dsc.last_fft_path(), []).append(n)
             assert rel_l2(Z.numpy(), np.fft.fft(zp, axis=-1)) <= tol, ('fft', n, ls, dsc.last_fft_path())
             assert rel_l2(dsc.ifft(Z).numpy(), zp) <= tol, ('ifft', n, ls, dsc.last_fft_path())
     # every kernel family must have been exercised by the sweep
-    need = {'generic_lds', 'regs_mid', 'r2c_2pass_regs', 'generic_4step'} | ({'r2c_64k_regs'} if dt == np.float32 else set())
+    need = {'generic_lds', 'regs_mid', 'r2c_2pass_regs', 'c2c_2pass_regs'} | ({'r2c_64k_regs'} if dt == np.float32 else set())
     assert need <= set(paths), paths.keys()
 
 

@@ -57,6 +57,9 @@ CASES['rfft_c5_f64_262144'] = _rfft_case(262144, 2048, f64=True)
 CASES['irfft_c5_f64_262144'] = _rfft_case(262144, 2048, f64=True, inverse=True)
 CASES['rfft_f32_131072'] = _rfft_case(131072, 4096)
 CASES['rfft_f32_524288'] = _rfft_case(524288, 1024)
+CASES['rfft_f32_1048576'] = _rfft_case(1048576, 512)
+CASES['rfft_f64_1048576'] = _rfft_case(1048576, 256, f64=True)
+CASES['fft_c32_524288'] = _fft_case(524288, 512)
 CASES['rfft_f32_262144'] = _rfft_case(262144, 2048)
 CASES['irfft_f32_262144'] = _rfft_case(262144, 2048, inverse=True)
 CASES['fft_c32_131072'] = _fft_case(131072, 2048)
