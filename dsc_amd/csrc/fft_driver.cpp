@@ -386,9 +386,12 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
     if (inner == 1 && !regs_mid_off && dsc_fft_regs_small_supports(j.L)) {            // 32 .. 256 points: LDS-staged register kernel
         const int x_n = j.x->shape[j.slot];
         const int want = j.mode == DSC_MODE_R2C_PACKED ? 2 * j.L : j.mode == DSC_MODE_C2R_PACKED ? j.L + 1 : j.L;
-        if (j.in_len == want && x_n == want) {
-            dsc_launch_fft_regs_mid(j.x->data, j.out->data, n_lines, j.L, j.mode, j.inverse, sp, plan->tw_full, plan->tw_real, j.scale, -1, 0,
-                                    ctx->stream);
+        const bool full = j.in_len == want && x_n == want;
+        // zero padded / cropped lines (frames of 200 samples transformed at 256 ...): the same kernel gathers line by line; 256-point
+        // lines take the mid kernel's PAD form below; the byte offsets of a group must fit 32 bits
+        if (full || (long long) x_n * 16 * 256 < (1LL << 30)) {
+            dsc_launch_fft_regs_mid(j.x->data, j.out->data, n_lines, j.L, j.mode, j.inverse, sp, plan->tw_full, plan->tw_real, j.scale,
+                                    full ? -1 : x_n, j.in_len, ctx->stream);
             ctx->last_fft_path = "regs_small";
             return;
         }

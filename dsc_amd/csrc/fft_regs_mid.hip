@@ -457,10 +457,13 @@ void launch_filter_len(int L, const void *s, const void *H, void *y, long long n
 template<typename R> struct small_cfg { static constexpr int NT = sizeof(R) == 8 ? 128 : 256; };
 template<typename R, int B> constexpr size_t small_lds_bytes() { return ((size_t) (small_cfg<R>::NT / B) * 33 * B + 32 * B + 32 * B + 2) * 2 * sizeof(R); }
 
-template<typename R, int B, int MODE, bool INV>
+// PAD: the input lines have a pitch of in_pitch BYTES of which in_len BYTES are valid (a packed-real line may hold an odd number of
+// samples: the pair that straddles its end keeps the first sample only); the rest of the transform length reads as zero
+// (zero padding / cropping through n=, dsc.cpp:1990-1998, 2125-2133, 2149-2157) — e.g. frames of 200 samples transformed at 256.
+template<typename R, int B, int MODE, bool INV, bool PAD>
 __global__ __launch_bounds__(small_cfg<R>::NT) void fft_small_kernel(const void *__restrict__ in, void *__restrict__ out, long long n_lines,
                                                                      const cpx<R> *__restrict__ tw_full, const cpx<R> *__restrict__ tw_real,
-                                                                     R scale) {
+                                                                     R scale, int in_pitch, int in_len) {
     using C = cpx<R>;
     constexpr int NT = small_cfg<R>::NT, L = 32 * B, G = NT / B, P = 33 * B, LOGB = ilog2(B);
     constexpr bool REAL_IN = MODE == DSC_MODE_R2C_CAST;
@@ -484,14 +487,29 @@ __global__ __launch_bounds__(small_cfg<R>::NT) void fft_small_kernel(const void 
     // Lines past the end of the batch read zeros (descriptor range).
     constexpr int CB = (int) sizeof(C), EB = REAL_IN ? (int) sizeof(R) : CB;
     constexpr int STEPS_IN = (G * IN_PITCH + NT - 1) / NT;                  // 32, or 33 for rows of L + 1 bins
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *) ((const char *) in + line0 * IN_PITCH * EB), 0,
-                                                                         n_valid * IN_PITCH * EB, 0x00020000);
+    const long long gpitch_b = PAD ? (long long) in_pitch : (long long) IN_PITCH * EB;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *) ((const char *) in + line0 * gpitch_b), 0,
+                                                                         (int) (PAD ? (n_valid - 1) * gpitch_b + in_len : n_valid * gpitch_b), 0x00020000);
     {
         C tmp[STEPS_IN];
+        if constexpr (PAD) {                                              // element (line, j) of the LDS image <- line * in_pitch + j, or zero
+            int line = tid / IN_PITCH, j = tid % IN_PITCH;
+#pragma unroll
+            for (int m = 0; m < STEPS_IN; ++m) {
+                const int voff = j * EB < in_len ? line * in_pitch + j * EB : 0x7f000000;
+                if constexpr (REAL_IN) tmp[m] = buf_load_real<kCached>(rin, voff, 0, R{});
+                else                   tmp[m] = buf_load<kCached>(rin, voff, 0, R{});
+                if (!REAL_IN && j * EB + EB > in_len) tmp[m].y = (R) 0;
+                j += NT % IN_PITCH;
+                line += NT / IN_PITCH;
+                if (j >= IN_PITCH) { j -= IN_PITCH; ++line; }
+            }
+        } else {
 #pragma unroll
         for (int m = 0; m < STEPS_IN; ++m) {
             if constexpr (REAL_IN) tmp[m] = buf_load_real<kStream>(rin, tid * EB, m * NT * EB, R{});
             else                   tmp[m] = buf_load<kCached>(rin, tid * EB, m * NT * EB, R{});
+        }
         }
         int line = tid / IN_PITCH, j = tid % IN_PITCH;
 #pragma unroll
@@ -562,28 +580,36 @@ __global__ __launch_bounds__(small_cfg<R>::NT) void fft_small_kernel(const void 
     }
 }
 
-template<typename R, int B, int MODE, bool INV>
-void launch_small_one(const void *in, void *out, long long n_lines, const void *tw_full, const void *tw_real, double scale, hipStream_t stream) {
+template<typename R, int B, int MODE, bool INV, bool PAD>
+void launch_small_pad(const void *in, void *out, long long n_lines, const void *tw_full, const void *tw_real, double scale, int in_pitch, int in_len,
+                      hipStream_t stream) {
     constexpr int G = small_cfg<R>::NT / B;
     constexpr size_t lds = small_lds_bytes<R, B>();
     static unsigned long long attr_devices = 0;
     if (dsc_first_use_on_device(attr_devices)) {
-        DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) fft_small_kernel<R, B, MODE, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) fft_small_kernel<R, B, MODE, INV, PAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     }
     const long long groups = (n_lines + G - 1) / G;
-    DSC_LAUNCH((fft_small_kernel<R, B, MODE, INV>), dim3((unsigned) groups), dim3(small_cfg<R>::NT), lds, stream, in, out, n_lines,
-                       (const cpx<R> *) tw_full, (const cpx<R> *) tw_real, (R) scale);
+    DSC_LAUNCH((fft_small_kernel<R, B, MODE, INV, PAD>), dim3((unsigned) groups), dim3(small_cfg<R>::NT), lds, stream, in, out, n_lines,
+                       (const cpx<R> *) tw_full, (const cpx<R> *) tw_real, (R) scale, in_pitch, in_len);
+}
+// in_pitch < 0: full contiguous lines
+template<typename R, int B, int MODE, bool INV>
+void launch_small_one(const void *in, void *out, long long n_lines, const void *tw_full, const void *tw_real, double scale, long long in_pitch, int in_len,
+                      hipStream_t stream) {
+    if (in_pitch < 0) launch_small_pad<R, B, MODE, INV, false>(in, out, n_lines, tw_full, tw_real, scale, 0, 0, stream);
+    else              launch_small_pad<R, B, MODE, INV, true>(in, out, n_lines, tw_full, tw_real, scale, (int) in_pitch, in_len, stream);
 }
 
 template<typename R, int B>
 void launch_small(const void *in, void *out, long long n_lines, dsc_fft_mode mode, bool inverse, const void *tw_full, const void *tw_real,
-                  double scale, hipStream_t stream) {
-    if (mode == DSC_MODE_R2C_PACKED)      launch_small_one<R, B, DSC_MODE_R2C_PACKED, false>(in, out, n_lines, tw_full, tw_real, scale, stream);
-    else if (mode == DSC_MODE_C2R_PACKED) launch_small_one<R, B, DSC_MODE_C2R_PACKED, true>(in, out, n_lines, tw_full, tw_real, scale, stream);
-    else if (mode == DSC_MODE_R2C_CAST && !inverse) launch_small_one<R, B, DSC_MODE_R2C_CAST, false>(in, out, n_lines, tw_full, tw_real, scale, stream);
-    else if (mode == DSC_MODE_R2C_CAST)   launch_small_one<R, B, DSC_MODE_R2C_CAST, true>(in, out, n_lines, tw_full, tw_real, scale, stream);
-    else if (inverse)                     launch_small_one<R, B, DSC_MODE_C2C, true>(in, out, n_lines, tw_full, tw_real, scale, stream);
-    else                                  launch_small_one<R, B, DSC_MODE_C2C, false>(in, out, n_lines, tw_full, tw_real, scale, stream);
+                  double scale, long long in_pitch, int in_len, hipStream_t stream) {
+    if (mode == DSC_MODE_R2C_PACKED)      launch_small_one<R, B, DSC_MODE_R2C_PACKED, false>(in, out, n_lines, tw_full, tw_real, scale, in_pitch, in_len, stream);
+    else if (mode == DSC_MODE_C2R_PACKED) launch_small_one<R, B, DSC_MODE_C2R_PACKED, true>(in, out, n_lines, tw_full, tw_real, scale, in_pitch, in_len, stream);
+    else if (mode == DSC_MODE_R2C_CAST && !inverse) launch_small_one<R, B, DSC_MODE_R2C_CAST, false>(in, out, n_lines, tw_full, tw_real, scale, in_pitch, in_len, stream);
+    else if (mode == DSC_MODE_R2C_CAST)   launch_small_one<R, B, DSC_MODE_R2C_CAST, true>(in, out, n_lines, tw_full, tw_real, scale, in_pitch, in_len, stream);
+    else if (inverse)                     launch_small_one<R, B, DSC_MODE_C2C, true>(in, out, n_lines, tw_full, tw_real, scale, in_pitch, in_len, stream);
+    else                                  launch_small_one<R, B, DSC_MODE_C2C, false>(in, out, n_lines, tw_full, tw_real, scale, in_pitch, in_len, stream);
 }
 
 template<typename R, int B, bool TWO, int MODE, bool INV, bool PAD>
@@ -648,17 +674,19 @@ static void launch_len(const void *in, void *out, long long n_lines, int L, dsc_
 void dsc_launch_fft_regs_mid(const void *in, void *out, long long n_lines, int L, dsc_fft_mode mode, bool inverse, bool single_precision,
                              const void *tw_full, const void *tw_real, double scale, long long in_pitch, int in_len, hipStream_t stream) {
     if (n_lines <= 0) return;
-    if (in_pitch < 0 && dsc_fft_regs_small_supports(L)) {       // full lines of 32 .. 256 points: the LDS-staged kernel
+    if (dsc_fft_regs_small_supports(L)) {                                   // 32 .. 256 points: the LDS-staged kernel
+        const int eb = (single_precision ? 4 : 8) * ((mode == DSC_MODE_R2C_PACKED || mode == DSC_MODE_R2C_CAST) ? 1 : 2);
+        if (in_pitch >= 0) { in_pitch *= eb; in_len *= eb; }                  // the kernel counts bytes
         if (single_precision) {
-            if (L == 32)       launch_small<float, 1>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream);
-            else if (L == 64)  launch_small<float, 2>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream);
-            else if (L == 128) launch_small<float, 4>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream);
-            else               launch_small<float, 8>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream);
+            if (L == 32)       launch_small<float, 1>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, in_pitch, in_len, stream);
+            else if (L == 64)  launch_small<float, 2>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, in_pitch, in_len, stream);
+            else if (L == 128) launch_small<float, 4>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, in_pitch, in_len, stream);
+            else               launch_small<float, 8>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, in_pitch, in_len, stream);
         } else {
-            if (L == 32)       launch_small<double, 1>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream);
-            else if (L == 64)  launch_small<double, 2>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream);
-            else if (L == 128) launch_small<double, 4>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream);
-            else               launch_small<double, 8>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, stream);
+            if (L == 32)       launch_small<double, 1>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, in_pitch, in_len, stream);
+            else if (L == 64)  launch_small<double, 2>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, in_pitch, in_len, stream);
+            else if (L == 128) launch_small<double, 4>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, in_pitch, in_len, stream);
+            else               launch_small<double, 8>(in, out, n_lines, mode, inverse, tw_full, tw_real, scale, in_pitch, in_len, stream);
         }
         return;
     }
