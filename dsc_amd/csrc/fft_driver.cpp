@@ -267,9 +267,11 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
     // back (32 x 32 LDS tiles), transform contiguous rows, transpose the result back — three streaming passes instead of
     // one latency-bound strided pass (measured 1.3-4x faster from 512 points up; below that the strided LDS kernel wins).
     static const bool via_transpose_off = getenv("DSC_NO_AXIS_TRANSPOSE") != nullptr;
-    if (inner > 1 && !via_transpose_off && j.L >= 512 &&
-        (dsc_fft_regs_mid_supports(j.L, j.mode, sp) || ((packed || j.mode == DSC_MODE_C2C) && dsc_fft_two_pass_supports(j.L, sp)) ||
-         (sp && packed && j.L == 32768))) {
+    const bool is_cast = j.mode == DSC_MODE_R2C_CAST;
+    const bool last_axis_kernel =                          // is there a register kernel for contiguous rows of this length and mode?
+        dsc_fft_regs_mid_supports(j.L, j.mode, sp) || ((packed || j.mode == DSC_MODE_C2C) && dsc_fft_two_pass_supports(j.L, sp)) ||
+        (sp && j.L == 32768) || dsc_fft_fused_l2_supports(j.L, sp, packed, j.inverse) || (is_cast && j.L == 262144);
+    if (inner > 1 && !via_transpose_off && j.L >= 512 && last_axis_kernel) {
         const int x_n = j.x->shape[j.slot], out_n = j.out->shape[j.slot];
         const long long outer = n_lines / inner;
         // the route needs two full-size temporaries in the main arena; a context sized for x and out only keeps the strided

@@ -136,7 +136,7 @@ __global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO,
     using cfg = cols_cfg<R, B, TWO, CW>;
     constexpr int T = cfg::T, L = cfg::L, NT = cfg::NT, CPT = cfg::CPT, COLS = cfg::COLS, LOGB = ilog2(B);
     constexpr int CB = (int) sizeof(C), RB = (int) sizeof(R);
-    constexpr int IB = MODE == DSC_MODE_R2C_PACKED ? RB : CB;       // bytes per input element
+    constexpr int IB = (MODE == DSC_MODE_R2C_PACKED || MODE == DSC_MODE_R2C_CAST) ? RB : CB;       // bytes per input element
     constexpr int OB = MODE == DSC_MODE_C2R_PACKED ? RB : CB;       // bytes per output element
     constexpr int kOut = 0x7f000000;                                // an offset past every descriptor range: reads 0, stores dropped
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -168,6 +168,11 @@ __global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO,
             const cpx<R> a = buf_load_real<kStream>(rin, voff, j1 * step, R{}), b = buf_load_real<kStream>(rin, voff, j1 * step + row_b, R{});
             v[j1] = C{a.x, b.x};
         }
+    } else if constexpr (MODE == DSC_MODE_R2C_CAST) {               // dsc_fft / dsc_ifft of a real tensor: widened while loading
+        const int voff = live ? (t * inner + col) * RB : kOut;
+        const int step = T * inner * RB;
+#pragma unroll
+        for (int j1 = 0; j1 < 32; ++j1) v[j1] = buf_load_real<kStream>(rin, voff, j1 * step, R{});
     } else {
         const int voff = live ? (t * inner + col) * CB : kOut;
         const int step = T * inner * CB;
@@ -218,7 +223,7 @@ __global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO,
 
     cols_passes<R, B, TWO, CW, INV>(v, plane, wtab, tw_full, t, c);
 
-    if constexpr (MODE == DSC_MODE_C2C) {
+    if constexpr (MODE == DSC_MODE_C2C || MODE == DSC_MODE_R2C_CAST) {
         const int voff = live ? (t * inner + col) * CB : kOut;
         const int step = inner * CB;
 #pragma unroll
@@ -313,18 +318,19 @@ void launch_cols_mode(dsc_fft_mode mode, bool inverse, const void *in, void *out
                       const void *tw_full, const void *tw_real, double scale, hipStream_t stream) {
     if (mode == DSC_MODE_R2C_PACKED)      launch_cols_one<R, B, TWO, CW, DSC_MODE_R2C_PACKED, false>(in, out, slices, inner, in_axis, in_len, out_axis, tw_full, tw_real, scale, stream);
     else if (mode == DSC_MODE_C2R_PACKED) launch_cols_one<R, B, TWO, CW, DSC_MODE_C2R_PACKED, true>(in, out, slices, inner, in_axis, in_len, out_axis, tw_full, tw_real, scale, stream);
+    else if (mode == DSC_MODE_R2C_CAST && inverse) launch_cols_one<R, B, TWO, CW, DSC_MODE_R2C_CAST, true>(in, out, slices, inner, in_axis, in_len, out_axis, tw_full, tw_real, scale, stream);
+    else if (mode == DSC_MODE_R2C_CAST)   launch_cols_one<R, B, TWO, CW, DSC_MODE_R2C_CAST, false>(in, out, slices, inner, in_axis, in_len, out_axis, tw_full, tw_real, scale, stream);
     else if (inverse)                     launch_cols_one<R, B, TWO, CW, DSC_MODE_C2C, true>(in, out, slices, inner, in_axis, in_len, out_axis, tw_full, tw_real, scale, stream);
     else                                  launch_cols_one<R, B, TWO, CW, DSC_MODE_C2C, false>(in, out, slices, inner, in_axis, in_len, out_axis, tw_full, tw_real, scale, stream);
 }
 
 }  // namespace
 
-// Complex lengths with a column kernel.  32 .. 2048, and 4096 for c32 data.  Modes: C2C, R2C_PACKED, C2R_PACKED (a real
-// tensor through dsc_fft — R2C_CAST — keeps the transpose route).
+// Complex lengths with a column kernel.  32 .. 2048, and 4096 for c32 data.  Modes: C2C, R2C_CAST (a real tensor through dsc_fft /
+// dsc_ifft, widened while loading), R2C_PACKED, C2R_PACKED.
 bool dsc_fft_regs_cols_supports(int L, dsc_fft_mode mode, bool single_precision) {
-    if (mode == DSC_MODE_R2C_CAST) return false;
     if (L == 32 || L == 64 || L == 128 || L == 256 || L == 512 || L == 1024 || L == 2048) return true;
-    return L == 4096 && single_precision && mode == DSC_MODE_C2C;      // 8 columns per tile: the real modes lose to the transpose route there
+    return L == 4096 && single_precision && mode == DSC_MODE_C2C;      // 8 columns per tile: the real modes (4-B samples: 32-B pieces) lose to the transpose route there
 }
 
 // Tensor [slices][axis][inner] (contiguous), transform along `axis`: in has in_axis elements along it of which in_len are

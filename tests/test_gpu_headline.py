@@ -759,6 +759,26 @@ def test_short_padded_and_cropped_lines_on_the_staged_register_kernel(dsc, dt):
                 assert_close(b.numpy(), port.irfft(Y, bins), what=f'irfft bins={bins} lb={lb}')
 
 
+@pytest.mark.parametrize('dt', [np.float32, np.float64])
+def test_fft_of_real_tensors_along_strided_axes(dsc, dt):
+    """dsc_fft / dsc_ifft of a REAL tensor along a non-last axis (the cast of dsc.cpp:1984-1988 happens in the gather): the column kernel
+    widens while loading (32 .. 2048 points), longer lines go through the transposes to the last-axis kernels, which do the same."""
+    from oracle import port
+    rng = np.random.default_rng(77)
+    for n, want in ((64, 'regs_cols'), (1024, 'regs_cols'), (8192, 'regs_mid'), (65536, 'c2c_fused_l2')):
+        cols = 24 if n >= 8192 else 120
+        for ls in (n, n - 5):
+            x = rng.standard_normal((ls, cols)).astype(dt)
+            F = dsc.fft(dsc.from_numpy(x), n=n, axis=0)
+            assert dsc.last_fft_path() == want, (n, dsc.last_fft_path())
+            assert_close(F.numpy(), port.fft(x, n, 0), what=f'fft(real) axis 0 n={n} ls={ls}')
+            G = dsc.ifft(dsc.from_numpy(x), n=n, axis=0)
+            assert_close(G.numpy(), port.ifft(x, n, 0), what=f'ifft(real) axis 0 n={n} ls={ls}')
+    x3 = rng.standard_normal((5, 256, 37)).astype(dt)
+    assert_close(dsc.fft(dsc.from_numpy(x3), axis=1).numpy(), port.fft(x3, -1, 1), what='fft(real) middle axis')
+    assert dsc.last_fft_path() == 'regs_cols'
+
+
 def test_generic_four_step_beyond_the_two_pass_lengths(dsc):
     """Rows longer than the two-kernel route covers (complex length above 2^20) still go through the generic four-step path."""
     rng = np.random.default_rng(22)

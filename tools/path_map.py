@@ -37,7 +37,7 @@ def run(op, dt, n, pad=False):
 
 
 names = {D.F32: 'f32', D.F64: 'f64', D.C32: 'c32', D.C64: 'c64'}
-for op, dts in (('rfft', (D.F32, D.F64)), ('irfft', (D.F32, D.F64)), ('fft', (D.C32, D.C64, D.F32, D.F64)), ('ifft', (D.C32, D.F32))):
+for op, dts in () if (len(sys.argv) > 1 and sys.argv[1] == 'axis0') else (('rfft', (D.F32, D.F64)), ('irfft', (D.F32, D.F64)), ('fft', (D.C32, D.C64, D.F32, D.F64)), ('ifft', (D.C32, D.F32))):
     for dt in dts:
         for pad in (False, True):
             cells = []
@@ -51,3 +51,39 @@ for op, dts in (('rfft', (D.F32, D.F64)), ('irfft', (D.F32, D.F64)), ('fft', (D.
                 except Exception as e:
                     cells.append(f'{n}:ERR')
             print(op, names[dt], 'padded' if pad else 'full', ' '.join(cells), flush=True)
+
+
+def run0(op, dt, n):
+    """the same along axis 0 of a [n, cols] tensor (strided lines)"""
+    in_dt = dt
+    if op == 'rfft':
+        out_dt = D.C32 if dt == D.F32 else D.C64; in_n, out_n = n, n // 2 + 1
+    elif op == 'irfft':
+        in_dt = D.C32 if dt == D.F32 else D.C64; out_dt = dt; in_n, out_n = n // 2 + 1, n
+    else:
+        out_dt = D.C32 if dt in (D.F32, D.C32) else D.C64; in_n, out_n = n, n
+    cols = max(8, (128 << 20) // (in_n * SZ[in_dt]))
+    x = dsc.empty((in_n, cols), in_dt)
+    y = dsc.empty((out_n, cols), out_dt)
+    f = getattr(B, 'dsc_' + op)
+    call = lambda: f(ctx, x._c_ptr, y._c_ptr, -1, 0)
+    for _ in range(2): call()
+    dsc.synchronize()
+    B.dsc_timer_start(ctx)
+    for _ in range(5): call()
+    ms = B.dsc_timer_stop(ctx) / 5
+    return dsc.last_fft_path(), cols * (in_n * SZ[in_dt] + out_n * SZ[out_dt]) / ms / 1e6 / 80
+
+
+if len(sys.argv) > 1 and sys.argv[1] == 'axis0':
+    for op, dts in (('rfft', (D.F32, D.F64)), ('irfft', (D.F32,)), ('fft', (D.C32, D.C64, D.F32)), ('ifft', (D.C32,))):
+        for dt in dts:
+            cells = []
+            for lg in range(2, 18):
+                n = 1 << lg
+                try:
+                    p, frac = run0(op, dt, n)
+                    cells.append(f'{n}:{p}:{frac:.0f}')
+                except Exception as e:
+                    cells.append(f'{n}:ERR')
+            print('axis0', op, names[dt], ' '.join(cells), flush=True)
