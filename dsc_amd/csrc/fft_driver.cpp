@@ -383,6 +383,19 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
         }
     }
 
+    // complex lengths 2 .. 16: one thread per line (fft_tiny.hip)
+    static const bool tiny_off = getenv("DSC_NO_TINY") != nullptr;                // A/B aid
+    if (inner == 1 && !tiny_off && dsc_fft_tiny_supports(j.L)) {
+        const int x_n = j.x->shape[j.slot];
+        const int want = j.mode == DSC_MODE_R2C_PACKED ? 2 * j.L : j.mode == DSC_MODE_C2R_PACKED ? j.L + 1 : j.L;
+        const bool full = j.in_len == want && x_n == want;
+        if (full || (long long) x_n * 16 * 256 < (1LL << 30)) {                  // byte offsets of a padded group fit 32 bits
+            dsc_launch_fft_tiny(j.x->data, j.out->data, n_lines, j.L, j.mode, j.inverse, sp, j.scale, full ? -1 : x_n, j.in_len, ctx->stream);
+            ctx->last_fft_path = "regs_tiny";
+            return;
+        }
+    }
+
     // register-resident mid sizes: contiguous full lines along the last axis
     static const bool regs_mid_off = getenv("DSC_NO_REGS_MID") != nullptr;      // A/B aid (tools/bench_mid.py)
     if (inner == 1 && !regs_mid_off && dsc_fft_regs_small_supports(j.L)) {            // 32 .. 256 points: LDS-staged register kernel

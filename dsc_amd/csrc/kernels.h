@@ -134,6 +134,12 @@ size_t dsc_fft_fused_l2_scratch_bytes(int L, bool single_precision);
 bool   dsc_launch_fft_fused_l2(const void *in, void *out, long long rows, int L, bool real, bool inverse, bool cast, bool single_precision, void *scratch,
                                unsigned *host_error, const void *tw_full, const void *tw_real, long long in_pitch, int in_len, hipStream_t stream);
 
+// ---- complex lengths 2 .. 16 (real 4 .. 32), contiguous lines, one thread per line (fft_tiny.hip).  in_pitch / in_len in input
+// elements (reals for R2C_PACKED / R2C_CAST), in_pitch < 0 = full lines; scale multiplies the results.
+bool dsc_fft_tiny_supports(int L);
+void dsc_launch_fft_tiny(const void *in, void *out, long long n_lines, int L, dsc_fft_mode mode, bool inverse, bool single_precision, double scale,
+                         long long in_pitch, int in_len, hipStream_t stream);
+
 // ---- register-resident transforms of contiguous full lines, complex length 256 .. 16384 (f32, f64; f32 C2C also 32768)
 // (fft_regs_mid.hip).  in / out: [n_lines][L] complex (C2C), [n_lines][2L] reals -> [n_lines][L+1] bins
 // (R2C_PACKED) or the converse (C2R_PACKED).  tw_full: W_L^k, k < L; tw_real: W_{2L}^k, k <= L.

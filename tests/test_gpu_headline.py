@@ -779,6 +779,38 @@ def test_fft_of_real_tensors_along_strided_axes(dsc, dt):
     assert dsc.last_fft_path() == 'regs_cols'
 
 
+@pytest.mark.parametrize('dt', [np.float32, np.float64])
+def test_tiny_lengths_one_thread_per_line(dsc, dt):
+    """Complex lengths 2 .. 16 (real 4 .. 32): fft_tiny.hip, one thread per line, the packed-real pass on the thread's own registers.
+    Every transform, full / zero-padded / cropped lines, one line and many, against the oracle."""
+    from oracle import port
+    rng = np.random.default_rng(16)
+    cdt = np.complex64 if dt == np.float32 else np.complex128
+    for n in (4, 8, 16, 32):
+        for ls in sorted({n, n - 1, 3, n + 5}):
+            for rows in (1, 1500):
+                x = rng.standard_normal((rows, ls)).astype(dt)
+                X = dsc.rfft(dsc.from_numpy(x), n=n)
+                assert dsc.last_fft_path() == 'regs_tiny', (n, ls, dsc.last_fft_path())
+                assert_close(X.numpy(), port.rfft(x, n), what=f'rfft n={n} ls={ls} rows={rows}')
+                bins = n // 2 + 1
+                lb = max(2, min(ls, bins + 2))
+                Y = (rng.standard_normal((rows, lb)) + 1j * rng.standard_normal((rows, lb))).astype(cdt)
+                b = dsc.irfft(dsc.from_numpy(Y), n=bins)
+                assert dsc.last_fft_path() == 'regs_tiny'
+                assert_close(b.numpy(), port.irfft(Y, bins), what=f'irfft bins={bins} lb={lb}')
+                if n <= 16:
+                    z = (rng.standard_normal((rows, ls)) + 1j * rng.standard_normal((rows, ls))).astype(cdt)
+                    assert_close(dsc.fft(dsc.from_numpy(z), n=n).numpy(), port.fft(z, n), what=f'fft n={n} ls={ls}')
+                    assert dsc.last_fft_path() == 'regs_tiny'
+                    assert_close(dsc.ifft(dsc.from_numpy(z), n=n).numpy(), port.ifft(z, n), what=f'ifft n={n} ls={ls}')
+                    assert_close(dsc.fft(dsc.from_numpy(x), n=n).numpy(), port.fft(x, n), what=f'fft(real) n={n} ls={ls}')
+    # a batch with leading dimensions
+    x4 = rng.standard_normal((3, 5, 7, 16)).astype(dt)
+    assert_close(dsc.rfft(dsc.from_numpy(x4)).numpy(), port.rfft(x4), what='rfft 4-d')
+    assert dsc.last_fft_path() == 'regs_tiny'
+
+
 def test_generic_four_step_beyond_the_two_pass_lengths(dsc):
     """Rows longer than the two-kernel route covers (complex length above 2^20) still go through the generic four-step path."""
     rng = np.random.default_rng(22)

@@ -7,8 +7,8 @@ ok = True
 for dt in (np.float32, np.float64):
     tol = 2e-6 if dt == np.float32 else 2e-14
     cdt = np.complex64 if dt == np.float32 else np.complex128
-    for n in (64, 128, 256, 512):
-        for ls in (n - 1, n - 37, n // 2 + 1, 3, n + 5, 2 * n):
+    for n in (4, 8, 16, 32, 64, 128, 256, 512):
+        for ls in sorted({n, max(1, n - 1), max(1, n - 37), n // 2 + 1, 3, n + 5, 2 * n}):
             for rows in (1, 7, 1000):
                 x = rng.standard_normal((rows, ls)).astype(dt)
                 got = dsc.rfft(dsc.from_numpy(x), n=n).numpy(); p = dsc.last_fft_path()
