@@ -125,6 +125,111 @@ __global__ __launch_bounds__(kTinyNT) void fft_tiny_kernel(const void *__restric
     }
 }
 
+// The same lengths along a NON-LAST axis of [slices][axis][inner]: neighbouring lines are contiguous, so a thread per line (lane = column)
+// loads and stores coalesced rows directly — no staging at all.  in_len valid elements of the input axis, the rest reads as zero; in_axis /
+// out_axis: the axis lengths of the two tensors, in their own element types.
+template<typename R, int L, int MODE, bool INV>
+__global__ __launch_bounds__(kTinyNT) void fft_tiny_cols_kernel(const void *__restrict__ in, void *__restrict__ out, int inner, int tiles_per_slice,
+                                                                int in_axis, int in_len, int out_axis, R scale) {
+    using C = cpx<R>;
+    constexpr int CB = (int) sizeof(C), RB = (int) sizeof(R), LOGL = ilog2(L);
+    constexpr int IB = (MODE == DSC_MODE_R2C_PACKED || MODE == DSC_MODE_R2C_CAST) ? RB : CB;
+    constexpr int OB = MODE == DSC_MODE_C2R_PACKED ? RB : CB;
+    constexpr int kOut = 0x7f000000;
+    const int slice = blockIdx.x / tiles_per_slice;
+    const int col = (blockIdx.x - slice * tiles_per_slice) * kTinyNT + threadIdx.x;
+    const bool live = col < inner;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+        (void *) ((const char *) in + (size_t) slice * in_axis * inner * IB), 0, in_len * inner * IB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
+        (void *) ((char *) out + (size_t) slice * out_axis * inner * OB), 0, out_axis * inner * OB, 0x00020000);
+    const int vin = live ? col * IB : kOut, vout = live ? col * OB : kOut;
+    const int irow = inner * IB, orow = inner * OB;
+
+    C v[32];
+    if constexpr (MODE == DSC_MODE_R2C_PACKED) {                            // z[m] = (x[2m], x[2m + 1]): two rows of the axis
+#pragma unroll
+        for (int m = 0; m < L; ++m) v[m] = C{buf_load_real<kStream>(rin, vin, 2 * m * irow, R{}).x, buf_load_real<kStream>(rin, vin, (2 * m + 1) * irow, R{}).x};
+    } else if constexpr (MODE == DSC_MODE_R2C_CAST) {
+#pragma unroll
+        for (int m = 0; m < L; ++m) v[m] = buf_load_real<kStream>(rin, vin, m * irow, R{});
+    } else if constexpr (MODE == DSC_MODE_C2R_PACKED) {                     // bins 0 .. L, pre-pass (dsc_fft.h:194-228)
+        C y[L + 1];
+#pragma unroll
+        for (int k = 0; k <= L; ++k) y[k] = buf_load<kStream>(rin, vin, k * irow, R{});
+#pragma unroll
+        for (int k = 0; k < L; ++k) {
+            C a = y[k], b = y[L - k];
+            if (k == 0) { a.y = (R) 0; b.y = (R) 0; }
+            const R wx = (R) w2l_re<L>(k), wy = (R) w2l_im<L>(k);
+            const R wqx = (R) 0.5 * wy, wqy = (R) 0.5 * wx;
+            const R sx = a.x + b.x, sy = a.y - b.y, dx = a.x - b.x, dy = a.y + b.y;
+            v[k] = C{(R) 0.5 * sx + (dx * wqx - dy * wqy), (R) 0.5 * sy + (dx * wqy + dy * wqx)};
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < L; ++m) v[m] = buf_load<kStream>(rin, vin, m * irow, R{});
+    }
+    dft_n<R, INV, L>(v);
+    if constexpr (MODE == DSC_MODE_R2C_PACKED) {
+#pragma unroll
+        for (int k = 0; k <= L; ++k) {
+            const C a = v[brev(k == L ? 0 : k, LOGL)], b = v[brev((k == 0 || k == L) ? 0 : L - k, LOGL)];
+            const R wx = (R) w2l_re<L>(k), wy = (R) w2l_im<L>(k);
+            const R wqx = (R) 0.5 * wy, wqy = (R) -0.5 * wx;
+            const R sx = a.x + b.x, sy = a.y - b.y, dx = a.x - b.x, dy = a.y + b.y;
+            C x = C{((R) 0.5 * sx + (dx * wqx - dy * wqy)) * scale, ((R) 0.5 * sy + (dx * wqy + dy * wqx)) * scale};
+            if (k == 0 || k == L) x.y = (R) 0;
+            buf_store<kStream>(x, rout, vout, k * orow);
+        }
+    } else if constexpr (MODE == DSC_MODE_C2R_PACKED) {                     // sample pair (2m, 2m + 1) = (re, im) of z[m]
+#pragma unroll
+        for (int m = 0; m < L; ++m) {
+            const C r = v[brev(m, LOGL)];
+            if constexpr (sizeof(R) == 4) {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r.x * scale), rout, vout, 2 * m * orow, kStream);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r.y * scale), rout, vout, (2 * m + 1) * orow, kStream);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, r.x * scale), rout, vout, 2 * m * orow, kStream);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, r.y * scale), rout, vout, (2 * m + 1) * orow, kStream);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < L; ++k) {
+            const C r = v[brev(k, LOGL)];
+            buf_store<kStream>(C{r.x * scale, r.y * scale}, rout, vout, k * orow);
+        }
+    }
+}
+
+template<typename R, int L, int MODE, bool INV>
+void launch_tiny_cols_one(const void *in, void *out, long long slices, int inner, int in_axis, int in_len, int out_axis, double scale, hipStream_t stream) {
+    const int tiles = (inner + kTinyNT - 1) / kTinyNT;
+    DSC_LAUNCH((fft_tiny_cols_kernel<R, L, MODE, INV>), dim3((unsigned) (slices * tiles)), dim3(kTinyNT), 0, stream, in, out, inner, tiles, in_axis, in_len,
+               out_axis, (R) scale);
+}
+template<typename R, int L>
+void launch_tiny_cols(const void *in, void *out, long long slices, int inner, int in_axis, int in_len, int out_axis, dsc_fft_mode mode, bool inverse,
+                      double scale, hipStream_t stream) {
+    if (mode == DSC_MODE_R2C_PACKED)      launch_tiny_cols_one<R, L, DSC_MODE_R2C_PACKED, false>(in, out, slices, inner, in_axis, in_len, out_axis, scale, stream);
+    else if (mode == DSC_MODE_C2R_PACKED) launch_tiny_cols_one<R, L, DSC_MODE_C2R_PACKED, true>(in, out, slices, inner, in_axis, in_len, out_axis, scale, stream);
+    else if (mode == DSC_MODE_R2C_CAST && !inverse) launch_tiny_cols_one<R, L, DSC_MODE_R2C_CAST, false>(in, out, slices, inner, in_axis, in_len, out_axis, scale, stream);
+    else if (mode == DSC_MODE_R2C_CAST)   launch_tiny_cols_one<R, L, DSC_MODE_R2C_CAST, true>(in, out, slices, inner, in_axis, in_len, out_axis, scale, stream);
+    else if (inverse)                     launch_tiny_cols_one<R, L, DSC_MODE_C2C, true>(in, out, slices, inner, in_axis, in_len, out_axis, scale, stream);
+    else                                  launch_tiny_cols_one<R, L, DSC_MODE_C2C, false>(in, out, slices, inner, in_axis, in_len, out_axis, scale, stream);
+}
+template<typename R>
+void launch_tiny_cols_len(int L, const void *in, void *out, long long slices, int inner, int in_axis, int in_len, int out_axis, dsc_fft_mode mode,
+                          bool inverse, double scale, hipStream_t stream) {
+    switch (L) {
+        case 2:  launch_tiny_cols<R, 2>(in, out, slices, inner, in_axis, in_len, out_axis, mode, inverse, scale, stream); break;
+        case 4:  launch_tiny_cols<R, 4>(in, out, slices, inner, in_axis, in_len, out_axis, mode, inverse, scale, stream); break;
+        case 8:  launch_tiny_cols<R, 8>(in, out, slices, inner, in_axis, in_len, out_axis, mode, inverse, scale, stream); break;
+        default: launch_tiny_cols<R, 16>(in, out, slices, inner, in_axis, in_len, out_axis, mode, inverse, scale, stream); break;
+    }
+}
+
 template<typename R, int L, int MODE, bool INV, bool PAD>
 void launch_tiny_pad(const void *in, void *out, long long n_lines, double scale, int in_pitch_b, int in_len_b, hipStream_t stream) {
     constexpr size_t lds = tiny_lds_bytes<R, L>();
@@ -177,4 +282,13 @@ void dsc_launch_fft_tiny(const void *in, void *out, long long n_lines, int L, ds
     const int lb = in_pitch < 0 ? 0 : in_len * eb;
     if (single_precision) launch_tiny_len<float>(L, in, out, n_lines, mode, inverse, scale, pb, lb, stream);
     else                  launch_tiny_len<double>(L, in, out, n_lines, mode, inverse, scale, pb, lb, stream);
+}
+
+// Tensor [slices][axis][inner] (contiguous), transform along `axis` (strided lines): in has in_axis elements along it of which in_len
+// are used, out has out_axis; element counts in each side's own element type.  Every slice must stay below 2 GiB: the caller checks.
+void dsc_launch_fft_tiny_cols(const void *in, void *out, long long slices, int inner, int L, dsc_fft_mode mode, bool inverse, bool single_precision,
+                              double scale, int in_axis, int in_len, int out_axis, hipStream_t stream) {
+    if (slices <= 0 || inner <= 0) return;
+    if (single_precision) launch_tiny_cols_len<float>(L, in, out, slices, inner, in_axis, in_len, out_axis, mode, inverse, scale, stream);
+    else                  launch_tiny_cols_len<double>(L, in, out, slices, inner, in_axis, in_len, out_axis, mode, inverse, scale, stream);
 }

@@ -137,6 +137,9 @@ bool   dsc_launch_fft_fused_l2(const void *in, void *out, long long rows, int L,
 // ---- complex lengths 2 .. 16 (real 4 .. 32), contiguous lines, one thread per line (fft_tiny.hip).  in_pitch / in_len in input
 // elements (reals for R2C_PACKED / R2C_CAST), in_pitch < 0 = full lines; scale multiplies the results.
 bool dsc_fft_tiny_supports(int L);
+// ... and along a non-last axis of [slices][axis][inner] (lane = column, no staging)
+void dsc_launch_fft_tiny_cols(const void *in, void *out, long long slices, int inner, int L, dsc_fft_mode mode, bool inverse, bool single_precision,
+                              double scale, int in_axis, int in_len, int out_axis, hipStream_t stream);
 void dsc_launch_fft_tiny(const void *in, void *out, long long n_lines, int L, dsc_fft_mode mode, bool inverse, bool single_precision, double scale,
                          long long in_pitch, int in_len, hipStream_t stream);
 

@@ -44,7 +44,11 @@ def test_paths_are_the_hand_written_kernels(dsc):
     assert dsc.last_fft_path() == 'generic_4step'
     dsc.rfft(dsc.from_numpy(np.ones((256, 8), np.float32)), axis=0)         # strided lines of 32 .. 2048 complex points: the column kernel
     assert dsc.last_fft_path() == 'regs_cols'
-    dsc.rfft(dsc.from_numpy(np.ones((32, 8), np.float32)), axis=0)          # shorter strided lines: the LDS line kernel
+    dsc.rfft(dsc.from_numpy(np.ones((32, 8), np.float32)), axis=0)          # shorter strided lines: one thread per line
+    assert dsc.last_fft_path() == 'regs_tiny_cols'
+    dsc.rfft(dsc.from_numpy(np.ones((8, 32), np.float32)))                  # ... and along the last axis
+    assert dsc.last_fft_path() == 'regs_tiny'
+    dsc.rfft(dsc.from_numpy(np.ones((8, 2), np.float32)))                   # one complex point: the LDS line kernel
     assert dsc.last_fft_path() == 'generic_lds'
 
 
@@ -805,6 +809,21 @@ def test_tiny_lengths_one_thread_per_line(dsc, dt):
                     assert dsc.last_fft_path() == 'regs_tiny'
                     assert_close(dsc.ifft(dsc.from_numpy(z), n=n).numpy(), port.ifft(z, n), what=f'ifft n={n} ls={ls}')
                     assert_close(dsc.fft(dsc.from_numpy(x), n=n).numpy(), port.fft(x, n), what=f'fft(real) n={n} ls={ls}')
+    # along a non-last axis: lane = column, no staging (fft_tiny_cols_kernel)
+    for n, ls, cols in ((8, 8, 1000), (16, 13, 37), (32, 35, 5)):
+        x = rng.standard_normal((ls, cols)).astype(dt)
+        assert_close(dsc.rfft(dsc.from_numpy(x), n=n, axis=0).numpy(), port.rfft(x, n, 0), what=f'rfft axis 0 n={n}')
+        assert dsc.last_fft_path() == 'regs_tiny_cols'
+        z = (rng.standard_normal((ls, cols)) + 1j * rng.standard_normal((ls, cols))).astype(cdt)
+        if n <= 16:
+            assert_close(dsc.ifft(dsc.from_numpy(z), n=n, axis=0).numpy(), port.ifft(z, n, 0), what=f'ifft axis 0 n={n}')
+            assert_close(dsc.fft(dsc.from_numpy(x), n=n, axis=0).numpy(), port.fft(x, n, 0), what=f'fft(real) axis 0 n={n}')
+        bins = n // 2 + 1
+        Y = z[:min(ls, bins)]
+        assert_close(dsc.irfft(dsc.from_numpy(np.ascontiguousarray(Y)), n=bins, axis=0).numpy(), port.irfft(np.ascontiguousarray(Y), bins, 0), what=f'irfft axis 0 n={n}')
+    x3 = rng.standard_normal((5, 16, 37)).astype(dt)
+    assert_close(dsc.rfft(dsc.from_numpy(x3), axis=1).numpy(), port.rfft(x3, -1, 1), what='rfft middle axis')
+    assert dsc.last_fft_path() == 'regs_tiny_cols'
     # a batch with leading dimensions
     x4 = rng.standard_normal((3, 5, 7, 16)).astype(dt)
     assert_close(dsc.rfft(dsc.from_numpy(x4)).numpy(), port.rfft(x4), what='rfft 4-d')
