@@ -102,7 +102,8 @@ def recorded_traffic(kernel, nbytes):
     kernel at the same algorithmic size, together with where and when it was measured; otherwise (None, None)."""
     tf = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
     try:
-        rec = json.load(open(tf)).get('kernels', {}).get(kernel)
+        recs = json.load(open(tf)).get('kernels', {})
+        rec = recs.get(f'{kernel}@{nbytes}') or recs.get(kernel)
         if rec and rec.get('algorithmic_bytes_per_launch') == nbytes:
             return rec['hbm_bytes_per_launch'], {'measured_in_this_run': False, 'file': 'profiles/traffic_latest.json',
                                                  'from': rec.get('source'), 'date': rec.get('date'), 'method': rec.get('method')}

@@ -72,7 +72,8 @@ CASES['irfft_f32_4096'] = _rfft_case(4096, 131072, inverse=True)
 CASES['rfft_f32_16384'] = _rfft_case(16384, 32768)
 CASES['rfft_f32_256'] = _rfft_case(256, 2097152)
 CASES['rfft_f64_4096'] = _rfft_case(4096, 65536, f64=True)
-CASES['rfft_f32_32'] = _rfft_case(32, 16777216)          # generic LDS kernel (complex length < 32)
+CASES['rfft_f32_32'] = _rfft_case(32, 16777216)          # one thread per line (fft_tiny.hip)
+CASES['rfft_f32_8'] = _rfft_case(8, 67108864)
 CASES['fft_c32_32768'] = _fft_case(32768, 8192)
 CASES['fft_c32_4096'] = _fft_case(4096, 65536)
 CASES['fft_c32_65536'] = _fft_case(65536, 4096)

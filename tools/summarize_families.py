@@ -99,7 +99,8 @@ for d in sorted(glob.glob(f'{out}/*/pmc1')):
         wb = sum(acc['WRITE_SIZE']) / len(acc['WRITE_SIZE']) * KB * w_corr
         alg = j['algorithmic_bytes']
         print(f'\nHBM bytes per launch: fetch {fb / 1e9:.4f} GB + write {wb / 1e9:.4f} GB = {(fb + wb) / 1e9:.4f} GB vs algorithmic {alg / 1e9:.4f} GB: x{(fb + wb) / alg:.3f}')
-        traffic[key.split('<')[0]] = {'hbm_bytes_per_launch': fb + wb, 'algorithmic_bytes_per_launch': alg, 'ratio': round((fb + wb) / alg, 4),
+        # one record per (kernel, size): template kernels serve several sizes (bench.py looks up `name@bytes` first)
+        traffic[key.split('<')[0]] = traffic[f"{key.split('<')[0]}@{alg}"] = {'hbm_bytes_per_launch': fb + wb, 'algorithmic_bytes_per_launch': alg, 'ratio': round((fb + wb) / alg, 4),
                                       'source': f'{out}/{c} (tools/profile_families.sh)', 'date': time.strftime('%Y-%m-%d'),
                                       'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected x%.4f / x%.4f on tools/calib_copy.hip' % (f_corr, w_corr)}
     if 'SQ_WAVE_CYCLES' in acc:
