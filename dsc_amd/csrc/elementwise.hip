@@ -245,10 +245,13 @@ __global__ void region_rows_kernel(const E *src, E *dst, const dsc_region r, uns
     const long long i0 = (long long) (i01 / r.count[1]), i1 = (long long) (i01 - (unsigned long long) i0 * r.count[1]);
     const long long base = r.base + i0 * r.stride[0] + i1 * r.stride[1] + i2 * r.stride[2];
     const long long dense0 = (long long) row * r.count[3];
-    const int c = chunk * blockDim.x + threadIdx.x;
-    if (c >= r.count[3]) return;
-    if (SCATTER) dst[base + c * r.stride[3]] = src[(dense0 + c) % dense_ne];
-    else         dst[dense0 + c] = src[base + c * r.stride[3]];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                                   // four elements per thread: 1024 per block
+        const int c = chunk * 1024 + u * 256 + threadIdx.x;
+        if (c >= r.count[3]) return;
+        if (SCATTER) dst[base + c * r.stride[3]] = src[(dense0 + c) % dense_ne];
+        else         dst[dense0 + c] = src[base + c * r.stride[3]];
+    }
 }
 
 template<typename E, bool SCATTER>
@@ -269,8 +272,8 @@ void region_typed(const void *src, void *dst, const dsc_region &r, bool scatter,
     const E *ps = (const E *) src;
     E *pd = (E *) dst;
     const long long rows = r.ne / r.count[3];
-    if (r.count[3] >= 128 && rows * ((r.count[3] + 255) / 256) < (1LL << 31)) {
-        const unsigned chunks = (unsigned) ((r.count[3] + 255) / 256);
+    if (r.count[3] >= 128 && rows * ((r.count[3] + 1023) / 1024) < (1LL << 31)) {
+        const unsigned chunks = (unsigned) ((r.count[3] + 1023) / 1024);
         const dim3 grid((unsigned) (rows * chunks));
         if (scatter) DSC_LAUNCH((region_rows_kernel<E, true>), grid, dim3(256), 0, s, ps, pd, r, chunks, dense_ne);
         else         DSC_LAUNCH((region_rows_kernel<E, false>), grid, dim3(256), 0, s, ps, pd, r, chunks, dense_ne);
@@ -286,6 +289,22 @@ void region_typed(const void *src, void *dst, const dsc_region &r, bool scatter,
 void dsc_launch_region_copy(const void *src, void *dst, int elem_bytes, const dsc_region &r, bool scatter, long long dense_ne,
                             hipStream_t stream) {
     if (r.ne <= 0) return;
+    // contiguous innermost rows whose ends fall on 16-byte boundaries (x[:, :60000], x[::2], a crop after irfft ...): move 16 bytes
+    // per lane instead of one element
+    const int V = 16 / elem_bytes;
+    if (V > 1 && r.stride[3] == 1 && dense_ne == r.ne && r.count[3] % V == 0 && r.base % V == 0 && (((size_t) src | (size_t) dst) & 15) == 0) {
+        bool ok = true;
+        for (int k = 0; k < 3; ++k) ok = ok && (r.count[k] == 1 || r.stride[k] % V == 0);
+        if (ok) {
+            dsc_region w = r;
+            w.base = r.base / V;
+            w.count[3] = r.count[3] / V;
+            for (int k = 0; k < 3; ++k) w.stride[k] = r.stride[k] / V;
+            w.ne = r.ne / V;
+            region_typed<b16>(src, dst, w, scatter, dense_ne / V, stream);
+            return;
+        }
+    }
     switch (elem_bytes) {
         case 4:  region_typed<unsigned int>(src, dst, r, scatter, dense_ne, stream); break;
         case 8:  region_typed<unsigned long long>(src, dst, r, scatter, dense_ne, stream); break;
@@ -327,6 +346,80 @@ void transpose_typed(const void *in, void *out, long long batch, int rows, int c
 }
 
 }  // namespace
+
+// ---- any permutation that moves the LAST axis (dsc_transpose with the reversed default, (2, 0, 1), ...): the plane spanned by the
+// input's last axis (c, stride 1 in the input) and the input axis that becomes the output's last axis (a, stride 1 in the output) is
+// transposed in 32 x 32 LDS tiles, both sides coalesced; the remaining (at most two) axes are a batch with their own strides.
+namespace {
+
+struct tr_plan {
+    int na, nc;                 // extents along a and c
+    long long sa_in, sc_out;    // input stride of a, output stride of c (elements)
+    int nb0, nb1;               // batch extents
+    long long b0_in, b0_out, b1_in, b1_out;
+};
+
+template<typename E>
+__global__ void transpose_plane_kernel(const E *in, E *out, tr_plan p, unsigned tiles_a, unsigned tiles_c) {
+    __shared__ E tile[32][33];
+    unsigned long long blk = blockIdx.x;
+    const unsigned tc = (unsigned) (blk % tiles_c); blk /= tiles_c;
+    const unsigned ta = (unsigned) (blk % tiles_a); blk /= tiles_a;
+    const unsigned i0 = (unsigned) (blk % (unsigned) p.nb0), i1 = (unsigned) (blk / (unsigned) p.nb0);
+    const E *src = in + i0 * p.b0_in + i1 * p.b1_in;
+    E *dst = out + i0 * p.b0_out + i1 * p.b1_out;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;              // 32 x 8 threads
+    for (int k = ty; k < 32; k += 8) {
+        const int a = ta * 32 + k, c = tc * 32 + tx;
+        if (a < p.na && c < p.nc) tile[k][tx] = src[a * p.sa_in + c];
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = tc * 32 + k, a = ta * 32 + tx;
+        if (a < p.na && c < p.nc) dst[c * p.sc_out + a] = tile[tx][k];
+    }
+}
+
+template<typename E>
+void transpose_plane_typed(const void *in, void *out, const tr_plan &p, hipStream_t s) {
+    const unsigned tiles_a = (p.na + 31) / 32, tiles_c = (p.nc + 31) / 32;
+    const unsigned long long blocks = (unsigned long long) tiles_a * tiles_c * p.nb0 * p.nb1;
+    DSC_LAUNCH((transpose_plane_kernel<E>), dim3((unsigned) blocks), dim3(256), 0, s, (const E *) in, (E *) out, p, tiles_a, tiles_c);
+}
+
+}  // namespace
+
+// shape / in_stride: the INPUT's extents and element strides per axis (n_dim <= 4, dense); perm: result axis i = input axis perm[i],
+// with perm[n_dim - 1] != n_dim - 1.  Returns false if the launch would not fit (the caller keeps the strided copy).
+bool dsc_launch_transpose_moving_last(const void *in, void *out, int elem_bytes, int n_dim, const int *shape, const int *in_stride, const int *perm,
+                                      hipStream_t stream) {
+    long long out_stride[4] = {1, 1, 1, 1};
+    for (int i = n_dim - 2; i >= 0; --i) out_stride[i] = out_stride[i + 1] * shape[perm[i + 1]];
+    const int a_axis = perm[n_dim - 1], c_axis = n_dim - 1;            // input axes of the tile plane
+    tr_plan p;
+    p.na = shape[a_axis]; p.nc = shape[c_axis];
+    p.sa_in = in_stride[a_axis];
+    p.sc_out = 1;
+    p.nb0 = p.nb1 = 1; p.b0_in = p.b0_out = p.b1_in = p.b1_out = 0;
+    int nb = 0;
+    for (int i = 0; i < n_dim; ++i) {                                   // result axis i <- input axis perm[i]
+        const int ax = perm[i];
+        if (ax == c_axis) { p.sc_out = out_stride[i]; continue; }
+        if (ax == a_axis) continue;
+        if (nb == 0) { p.nb0 = shape[ax]; p.b0_in = in_stride[ax]; p.b0_out = out_stride[i]; }
+        else         { p.nb1 = shape[ax]; p.b1_in = in_stride[ax]; p.b1_out = out_stride[i]; }
+        ++nb;
+    }
+    const unsigned long long blocks = (unsigned long long) ((p.na + 31) / 32) * ((p.nc + 31) / 32) * p.nb0 * p.nb1;
+    if (blocks == 0) return true;
+    if (blocks > 0x7fffffffull) return false;
+    switch (elem_bytes) {
+        case 4:  transpose_plane_typed<unsigned int>(in, out, p, stream); break;
+        case 8:  transpose_plane_typed<unsigned long long>(in, out, p, stream); break;
+        default: transpose_plane_typed<b16>(in, out, p, stream); break;
+    }
+    return true;
+}
 
 void dsc_launch_transpose_last2(const void *in, void *out, int elem_bytes, long long batch, int rows, int cols, hipStream_t stream) {
     if (batch <= 0 || rows <= 0 || cols <= 0) return;

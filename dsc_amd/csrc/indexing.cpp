@@ -274,7 +274,16 @@ extern "C" dsc_tensor *dsc_transpose(dsc_ctx *ctx, const dsc_tensor *x, int axes
         const int rows = x->shape[DSC_MAX_DIMS - 2], cols = x->shape[DSC_MAX_DIMS - 1];
         dsc_launch_transpose_last2(x->data, out->data, esz, (long long) x->ne / ((long long) rows * cols), rows, cols, ctx->stream);
     } else {
-        dsc_launch_region_copy(x->data, out->data, esz, src, false, out->ne, ctx->stream);
+        // the last axis moves: tile the plane it spans with the axis that takes its place (both sides coalesced)
+        bool tiled = false;
+        if (perm[nd - 1] != nd - 1) {
+            int shape[DSC_MAX_DIMS], stride[DSC_MAX_DIMS];
+            for (int i = 0; i < nd; ++i) { shape[i] = x->shape[dsc_axis_slot(x, i)]; stride[i] = x->stride[dsc_axis_slot(x, i)]; }
+            bool distinct = true;                                        // a repeated axis number is not a permutation: the strided copy handles it
+            for (int i = 0; i < nd; ++i) for (int k = i + 1; k < nd; ++k) distinct = distinct && perm[i] != perm[k];
+            if (distinct) tiled = dsc_launch_transpose_moving_last(x->data, out->data, esz, nd, shape, stride, perm, ctx->stream);
+        }
+        if (!tiled) dsc_launch_region_copy(x->data, out->data, esz, src, false, out->ne, ctx->stream);
     }
     return out;
 }

@@ -201,3 +201,6 @@ void dsc_launch_region_copy(const void *src, void *dst, int elem_bytes, const ds
 
 // out[b][c][r] = in[b][r][c] for `batch` matrices of rows x cols elements (32 x 32 tiles through LDS: both sides coalesced)
 void dsc_launch_transpose_last2(const void *in, void *out, int elem_bytes, long long batch, int rows, int cols, hipStream_t stream);
+// any permutation that moves the last axis (n_dim <= 4, dense input): tiled through LDS, coalesced on both sides
+bool dsc_launch_transpose_moving_last(const void *in, void *out, int elem_bytes, int n_dim, const int *shape, const int *in_stride, const int *perm,
+                                      hipStream_t stream);
