@@ -106,6 +106,28 @@ __global__ void binary_kernel(const T *a, const T *b, T *out, const dsc_bcast_ar
     }
 }
 
+// general broadcast with a long innermost axis: a block owns a piece of one innermost row of the RESULT — one division chain per
+// block instead of one per element; along the row each operand advances by its own stride (1, or 0 where it is broadcast)
+template<typename T, int OP>
+__global__ void binary_rows_kernel(const T *a, const T *b, T *out, const dsc_bcast_args g, unsigned chunks_per_row) {
+    const unsigned long long blk = blockIdx.x;
+    const unsigned long long row = blk / chunks_per_row;
+    const unsigned chunk = (unsigned) (blk - row * chunks_per_row);
+    const unsigned long long i01 = row / (unsigned) g.out_shape[2];
+    const long long i2 = (long long) (row - i01 * (unsigned) g.out_shape[2]);
+    const long long i0 = (long long) (i01 / (unsigned) g.out_shape[1]), i1 = (long long) (i01 - (unsigned long long) i0 * (unsigned) g.out_shape[1]);
+    const T *pa = a + (i0 * g.a_stride[0] + i1 * g.a_stride[1] + i2 * g.a_stride[2]);
+    const T *pb = b + (i0 * g.b_stride[0] + i1 * g.b_stride[1] + i2 * g.b_stride[2]);
+    T *po = out + (long long) row * g.out_shape[3];
+    const long long sa = g.a_stride[3], sb = g.b_stride[3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = chunk * 1024 + u * 256 + threadIdx.x;
+        if (c >= g.out_shape[3]) return;
+        po[c] = apply<T, OP>(pa[c * sa], pb[c * sb]);
+    }
+}
+
 // equal shapes: 16 bytes per lane and operand (V = 16 / sizeof(T) elements), the widest global access
 template<typename T, int OP>
 __global__ void binary_same_vec_kernel(const T *a, const T *b, T *out, unsigned nvec) {
@@ -147,6 +169,18 @@ void binary_typed(const void *a, const void *b, void *out, int op, const dsc_bca
     if (op == 1 && binary_fast<T, 1>(pa, pb, po, g, grid, s)) return;
     if (op == 2 && binary_fast<T, 2>(pa, pb, po, g, grid, s)) return;
     if (op == 3 && binary_fast<T, 3>(pa, pb, po, g, grid, s)) return;
+    const long long rows = g.out_shape[3] > 0 ? g.ne / g.out_shape[3] : 0;
+    const unsigned chunks = (unsigned) ((g.out_shape[3] + 1023) / 1024);
+    if (!g.a_scalar && !g.b_scalar && g.out_shape[3] >= 64 && rows * chunks < (1LL << 31)) {
+        const dim3 rg((unsigned) (rows * chunks));
+        switch (op) {
+            case 0: DSC_LAUNCH((binary_rows_kernel<T, 0>), rg, dim3(256), 0, s, pa, pb, po, g, chunks); break;
+            case 1: DSC_LAUNCH((binary_rows_kernel<T, 1>), rg, dim3(256), 0, s, pa, pb, po, g, chunks); break;
+            case 2: DSC_LAUNCH((binary_rows_kernel<T, 2>), rg, dim3(256), 0, s, pa, pb, po, g, chunks); break;
+            default: DSC_LAUNCH((binary_rows_kernel<T, 3>), rg, dim3(256), 0, s, pa, pb, po, g, chunks); break;
+        }
+        return;
+    }
     switch (op) {
         case 0: DSC_LAUNCH((binary_kernel<T, 0>), grid, dim3(256), 0, s, pa, pb, po, g); break;
         case 1: DSC_LAUNCH((binary_kernel<T, 1>), grid, dim3(256), 0, s, pa, pb, po, g); break;

@@ -366,6 +366,25 @@ def test_golden_transpose_and_fftfreq(dsc, golden):
     assert rel_l2(a, b) <= 1e-6
 
 
+def test_general_broadcast_with_long_rows(dsc):
+    """Broadcast patterns that are neither equal shapes nor a trailing-dims operand (column vectors, operands broadcast along several
+    axes, both operands smaller than the result) on results with a long innermost axis: the row-wise kernel (one division chain per
+    block).  Every operator, all four dtypes, against the oracle."""
+    from oracle import port
+    rng = np.random.default_rng(91)
+    ops = ((dsc.add, port.ADD), (dsc.sub, port.SUB), (dsc.mul, port.MUL), (dsc.true_div, port.DIV))
+    for dt in (np.float32, np.float64, np.complex64, np.complex128):
+        for sa, sb in (((37, 1000), (37, 1)), ((5, 3, 70, 200), (5, 1, 70, 1)), ((3, 1, 129), (4, 1, 50, 1)), ((1, 2500), (6, 1)), ((6, 1), (1, 2500)),
+                       ((2, 3, 4, 64), (3, 1, 64))):
+            a = rng.standard_normal(sa).astype(dt)
+            b = (rng.standard_normal(sb) + 2.5).astype(dt)
+            if np.dtype(dt).kind == 'c':
+                a = (a + 1j * rng.standard_normal(sa)).astype(dt)
+                b = (b + 1j * rng.standard_normal(sb)).astype(dt)
+            for f, op in ops:
+                assert_close(f(dsc.from_numpy(a), dsc.from_numpy(b)).numpy(), port.binary(a, b, op), what=f'{f.__name__} {np.dtype(dt).name} {sa} x {sb}')
+
+
 def test_transpose_every_permutation_and_aligned_slices(dsc):
     """dsc_transpose for every permutation of 2 .. 4 axes (dsc.cpp:764-827; permutations that move the last axis go through 32 x 32 LDS
     tiles, the others through the strided copy) and slices whose rows start on 16-byte boundaries (moved 16 bytes per lane):
