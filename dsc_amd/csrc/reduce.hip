@@ -96,6 +96,7 @@ __global__ void reduce_seq_kernel(const void *x, void *out, long long outer, int
         const long long base = oo * axis_n * inner + ii;
         acc_t<R, CPLX> acc = acc_init<R, CPLX, OP>();
         acc.idx = 0;
+#pragma unroll 8
         for (int j = 0; j < axis_n; ++j) {
             const acc_t<R, CPLX> v = load_elem<R, CPLX>(x, base + (long long) j * inner, 0);
             if (OP <= 1) { acc.r = acc.r + v.r; acc.i = acc.i + v.i; }
@@ -203,6 +204,36 @@ __global__ __launch_bounds__(256) void reduce_row_kernel(const void *x, void *ou
     }
 }
 
+// Short rows (64 .. 2048 elements), many of them: one WAVE per row (four rows per workgroup), shuffles only — a 256-thread workgroup
+// per 4 KiB row spends its time in barriers (sum f32 [131072, 1024]: 42 % of the roofline).  Same NaN rules as reduce_row_kernel.
+template<typename R, bool CPLX, int OP>
+__global__ __launch_bounds__(256) void reduce_row_wave_kernel(const void *x, void *out, long long outer, int axis_n) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (long long row = (long long) blockIdx.x * 4 + w; row < outer; row += (long long) gridDim.x * 4) {
+        const long long base = row * axis_n;
+        acc_t<R, CPLX> acc = acc_init<R, CPLX, OP>();
+        int last_nan = -1;
+#pragma unroll 4
+        for (int j = lane; j < axis_n; j += 64) {
+            const acc_t<R, CPLX> v = load_elem<R, CPLX>(x, base + j, j);
+            if (OP >= 2 && v.r != v.r) last_nan = j;
+            else acc = combine<R, CPLX, OP>(acc, v);
+        }
+        for (int d = 32; d > 0; d >>= 1) acc = combine<R, CPLX, OP>(acc, shfl_down_acc<R, CPLX>(acc, d));
+        if (OP >= 2 && nan_wipes<OP, CPLX>()) {
+            for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_down(last_nan, d, 64); last_nan = o > last_nan ? o : last_nan; }
+            const int p = __shfl(last_nan, 0, 64);
+            if (p >= 0) {                                   // the reference's accumulator forgot everything up to the last NaN
+                acc = acc_init<R, CPLX, OP>();
+                for (int j = p + 1 + lane; j < axis_n; j += 64) acc = combine<R, CPLX, OP>(acc, load_elem<R, CPLX>(x, base + j, j));
+                for (int d = 32; d > 0; d >>= 1) acc = combine<R, CPLX, OP>(acc, shfl_down_acc<R, CPLX>(acc, d));
+                if (p == axis_n - 1) acc = load_elem<R, CPLX>(x, base + p, p);
+            }
+        }
+        if (lane == 0) store_elem<R, CPLX, OP>(out, row, acc, axis_n);
+    }
+}
+
 template<typename R, bool CPLX, int OP>
 void launch_op(const void *x, void *out, long long outer, int axis_n, long long inner, void *ws, size_t ws_bytes, hipStream_t s) {
     const long long n_out_all = outer * inner;
@@ -227,7 +258,11 @@ void launch_op(const void *x, void *out, long long outer, int axis_n, long long 
             return;
         }
     }
-    if (inner == 1 && axis_n >= 64) {
+    if (inner == 1 && axis_n >= 64 && axis_n <= 2048 && outer >= 1024) {
+        long long blocks = (outer + 3) / 4;
+        if (blocks > 256 * 32) blocks = 256 * 32;
+        DSC_LAUNCH((reduce_row_wave_kernel<R, CPLX, OP>), dim3((unsigned) blocks), dim3(256), 0, s, x, out, outer, axis_n);
+    } else if (inner == 1 && axis_n >= 64) {
         long long blocks = outer < 256 * 16 ? outer : 256 * 16;
         DSC_LAUNCH((reduce_row_kernel<R, CPLX, OP>), dim3((unsigned) blocks), dim3(256), 0, s, x, out, outer, axis_n);
     } else {
