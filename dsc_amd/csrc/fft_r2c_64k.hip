@@ -104,6 +104,7 @@ __device__ __forceinline__ cf mul_root(cf d) {
     }
 }
 
+#ifdef DSC_DFT32_DIF
 template<bool INV, int M, int G, int... K>
 __device__ __forceinline__ void dif_group(cf (&v)[32], std::integer_sequence<int, K...>) {
     (([&] {
@@ -129,6 +130,86 @@ __device__ __forceinline__ void dft32(cf (&v)[32]) {
     dif_stage<INV, 4>(v, std::make_integer_sequence<int, 8>{});
     dif_stage<INV, 2>(v, std::make_integer_sequence<int, 16>{});
 }
+
+
+#else
+// The same transform as the decimation-in-time graph with natural-order input and bit-reversed output: stage s (half distance
+// h = 32 >> s) has 2^(s-1) groups, group g multiplies the LOWER input of its butterflies by ONE constant e^{-i pi theta_g},
+// theta_g = bitrev(g) / 2^(s-1) (a DFT with frequency offset theta splits into offsets theta / 2 and (1 + theta) / 2), then
+// adds and subtracts.  A constant twiddle in front of the add / sub costs 6 fused multiply-adds instead of the 8 operations of
+// "subtract, then multiply" (Linzer & Feig): with w = c (1 + i t), p = b.x - t b.y, q = b.y + t b.x, out = a +- c (p, q); the
+// larger of |cos|, |sin| is factored out so that |t| <= 1.  34 of the 80 butterflies carry such a twiddle: 388 VALU
+// instructions per 32-point DFT instead of 456 — the fused filter, six of them per row, is bound by the vector ALUs.
+constexpr double kCos64d[17] = {
+    1.0, 0.99518472667219688624, 0.98078528040323044913, 0.95694033573220886494,
+    0.92387953251128675613, 0.88192126434835502971, 0.83146961230254523708, 0.77301045336273696081,
+    0.70710678118654752440, 0.63439328416364549822, 0.55557023301960222474, 0.47139673682599764856,
+    0.38268343236508977173, 0.29028467725446236764, 0.19509032201612826785, 0.09801714032956060199,
+    0.0};
+
+// a, b -> a + w b, a - w b with w = W_32^E (forward) or its conjugate (INV), 0 <= E < 16
+template<bool INV, int E>
+__device__ __forceinline__ void dit_butterfly(cf &a, cf &b) {
+    if constexpr (E == 0) {
+        const cf u = a + b, d = a - b;
+        a = u; b = d;
+    } else if constexpr (E == 8) {                          // w = -i (forward), +i (inverse)
+        const cf u = INV ? cf{a.x - b.y, a.y + b.x} : cf{a.x + b.y, a.y - b.x};
+        const cf d = INV ? cf{a.x + b.y, a.y - b.x} : cf{a.x - b.y, a.y + b.x};
+        a = u; b = d;
+    } else {
+        constexpr double c = E <= 8 ? kCos64d[2 * E] : -kCos64d[32 - 2 * E];            // cos(2 pi E / 32)
+        constexpr double sn = (E <= 8 ? kCos64d[16 - 2 * E] : kCos64d[2 * E - 16]);       // sin(2 pi E / 32) > 0
+        constexpr double s = INV ? sn : -sn;                                            // w = c + i s
+        if constexpr ((c < 0 ? -c : c) >= sn) {
+            constexpr float t = (float) (s / c), cc = (float) c;
+            float p, q;
+            if constexpr (t == 1.0f) { p = b.x - b.y; q = b.y + b.x; }
+            else if constexpr (t == -1.0f) { p = b.x + b.y; q = b.y - b.x; }
+            else { p = __builtin_fmaf(-t, b.y, b.x); q = __builtin_fmaf(t, b.x, b.y); }
+            const cf u = cf{__builtin_fmaf(cc, p, a.x), __builtin_fmaf(cc, q, a.y)};
+            const cf d = cf{__builtin_fmaf(-cc, p, a.x), __builtin_fmaf(-cc, q, a.y)};
+            a = u; b = d;
+        } else {                                            // w b = s (r b.x - b.y, r b.y + b.x), r = c / s
+            constexpr float r = (float) (c / s), ss = (float) s;
+            const float pn = __builtin_fmaf(-r, b.x, b.y);  // -(r b.x - b.y)
+            const float q = __builtin_fmaf(r, b.y, b.x);
+            const cf u = cf{__builtin_fmaf(-ss, pn, a.x), __builtin_fmaf(ss, q, a.y)};
+            const cf d = cf{__builtin_fmaf(ss, pn, a.x), __builtin_fmaf(-ss, q, a.y)};
+            a = u; b = d;
+        }
+    }
+}
+
+constexpr int brev_bits(int x, int bits) {
+    int r = 0;
+    for (int i = 0; i < bits; ++i) r |= ((x >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+
+// stage S = 1..5: H = 32 >> S, group G covers v[2 H G .. 2 H G + 2 H)
+template<bool INV, int S, int G, int... J>
+__device__ __forceinline__ void dit_group(cf (&v)[32], std::integer_sequence<int, J...>) {
+    constexpr int H = 32 >> S;
+    constexpr int E = brev_bits(G, S - 1) * (16 >> (S - 1));                            // W_32 exponent = 16 theta_g
+    (dit_butterfly<INV, E>(v[2 * H * G + J], v[2 * H * G + J + H]), ...);
+}
+
+template<bool INV, int S, int... G>
+__device__ __forceinline__ void dit_stage(cf (&v)[32], std::integer_sequence<int, G...>) {
+    (dit_group<INV, S, G>(v, std::make_integer_sequence<int, (32 >> S)>{}), ...);
+}
+
+// 32-point DFT, natural order in; v[p] returns bin br5(p).
+template<bool INV>
+__device__ __forceinline__ void dft32(cf (&v)[32]) {
+    dit_stage<INV, 1>(v, std::make_integer_sequence<int, 1>{});
+    dit_stage<INV, 2>(v, std::make_integer_sequence<int, 2>{});
+    dit_stage<INV, 3>(v, std::make_integer_sequence<int, 4>{});
+    dit_stage<INV, 4>(v, std::make_integer_sequence<int, 8>{});
+    dit_stage<INV, 5>(v, std::make_integer_sequence<int, 16>{});
+}
+#endif
 
 typedef unsigned int u2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));

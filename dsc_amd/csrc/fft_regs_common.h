@@ -60,6 +60,7 @@ __device__ __forceinline__ cpx<R> mul_root(cpx<R> d) {
     }
 }
 
+#ifdef DSC_DFT_DIF
 template<typename R, bool INV, int M, int G, int... K>
 __device__ __forceinline__ void dif_group(cpx<R> (&v)[32], std::integer_sequence<int, K...>) {
     (([&] {
@@ -83,6 +84,69 @@ __device__ __forceinline__ void dft_n(cpx<R> (&v)[32]) {
     if constexpr (N >= 4)  dif_stage<R, INV, 4, BASE>(v, std::make_integer_sequence<int, N / 4>{});
     dif_stage<R, INV, 2, BASE>(v, std::make_integer_sequence<int, N / 2>{});
 }
+#else
+// The decimation-in-time graph with natural-order input and bit-reversed output (same contract as the DIF form above): stage s
+// (half distance H = N >> s) has 2^(s-1) groups, group g multiplies the LOWER input of its butterflies by ONE constant
+// e^{-i pi theta_g}, theta_g = brev(g, s-1) / 2^(s-1) — a DFT with frequency offset theta splits into two of offsets theta / 2
+// and (1 + theta) / 2 — then adds and subtracts.  A constant twiddle in FRONT of the add / sub costs 6 fused multiply-adds
+// instead of the 8 operations of "subtract, then multiply" (Linzer & Feig): w = c (1 + i t), p = b.x - t b.y, q = b.y + t b.x,
+// out = a +- c (p, q); the larger of |cos|, |sin| is factored out so that |t| <= 1.
+__device__ __forceinline__ float fma_r(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_r(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// a, b -> a + w b, a - w b with w = W_64^Q (forward) or its conjugate (INV), 0 <= Q < 32
+template<typename R, bool INV, int Q>
+__device__ __forceinline__ void dit_butterfly(cpx<R> &a, cpx<R> &b) {
+    if constexpr (Q == 0) {
+        const cpx<R> u = a + b, d = a - b;
+        a = u; b = d;
+    } else if constexpr (Q == 16) {                         // w = -i (forward), +i (inverse)
+        const cpx<R> u = INV ? cpx<R>{a.x - b.y, a.y + b.x} : cpx<R>{a.x + b.y, a.y - b.x};
+        const cpx<R> d = INV ? cpx<R>{a.x + b.y, a.y - b.x} : cpx<R>{a.x - b.y, a.y + b.x};
+        a = u; b = d;
+    } else {
+        constexpr double c = root64_re(Q);
+        constexpr double s = INV ? -root64_im(Q) : root64_im(Q);                        // w = c + i s
+        if constexpr ((c < 0 ? -c : c) >= (s < 0 ? -s : s)) {
+            constexpr R t = (R) (s / c), cc = (R) c;
+            R p, q;
+            if constexpr (t == (R) 1) { p = b.x - b.y; q = b.y + b.x; }
+            else if constexpr (t == (R) -1) { p = b.x + b.y; q = b.y - b.x; }
+            else { p = fma_r(-t, b.y, b.x); q = fma_r(t, b.x, b.y); }
+            const cpx<R> u = cpx<R>{fma_r(cc, p, a.x), fma_r(cc, q, a.y)};
+            const cpx<R> d = cpx<R>{fma_r(-cc, p, a.x), fma_r(-cc, q, a.y)};
+            a = u; b = d;
+        } else {                                            // w b = s (r b.x - b.y, r b.y + b.x), r = c / s
+            constexpr R r = (R) (c / s), ss = (R) s;
+            const R pn = fma_r(-r, b.x, b.y);               // -(r b.x - b.y)
+            const R q = fma_r(r, b.y, b.x);
+            const cpx<R> u = cpx<R>{fma_r(-ss, pn, a.x), fma_r(ss, q, a.y)};
+            const cpx<R> d = cpx<R>{fma_r(ss, pn, a.x), fma_r(-ss, q, a.y)};
+            a = u; b = d;
+        }
+    }
+}
+// stage S = 1 .. log2 N of an N-point transform at v[BASE ..): H = N >> S, group G covers 2 H registers
+template<typename R, bool INV, int N, int S, int BASE, int G, int... J>
+__device__ __forceinline__ void dit_group(cpx<R> (&v)[32], std::integer_sequence<int, J...>) {
+    constexpr int H = N >> S;
+    constexpr int Q = (32 * brev(G, S - 1)) >> (S - 1);                                 // W_64 exponent = 32 theta_g
+    (dit_butterfly<R, INV, Q>(v[BASE + 2 * H * G + J], v[BASE + 2 * H * G + J + H]), ...);
+}
+template<typename R, bool INV, int N, int S, int BASE, int... G>
+__device__ __forceinline__ void dit_stage(cpx<R> (&v)[32], std::integer_sequence<int, G...>) {
+    (dit_group<R, INV, N, S, BASE, G>(v, std::make_integer_sequence<int, (N >> S)>{}), ...);
+}
+// N-point DFT (N = 2 .. 32) of v[BASE .. BASE+N), natural order in; v[BASE + p] returns bin brev(p, log2 N)
+template<typename R, bool INV, int N, int BASE = 0>
+__device__ __forceinline__ void dft_n(cpx<R> (&v)[32]) {
+    dit_stage<R, INV, N, 1, BASE>(v, std::make_integer_sequence<int, 1>{});
+    if constexpr (N >= 4)  dit_stage<R, INV, N, 2, BASE>(v, std::make_integer_sequence<int, 2>{});
+    if constexpr (N >= 8)  dit_stage<R, INV, N, 3, BASE>(v, std::make_integer_sequence<int, 4>{});
+    if constexpr (N >= 16) dit_stage<R, INV, N, 4, BASE>(v, std::make_integer_sequence<int, 8>{});
+    if constexpr (N >= 32) dit_stage<R, INV, N, 5, BASE>(v, std::make_integer_sequence<int, 16>{});
+}
+#endif
 template<typename R, bool INV, int N, int... I>
 __device__ __forceinline__ void dft_columns(cpx<R> (&v)[32], std::integer_sequence<int, I...>) {
     (dft_n<R, INV, N, I * N>(v), ...);
