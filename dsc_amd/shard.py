@@ -124,6 +124,7 @@ class ShardGather:
             from . import _bindings as B
             self._stream = torch.cuda.ExternalStream(B.dsc_stream(ctx))
         self._mapped = None
+        self._failed = None
         if method == 'ipc':
             if not (self.on_gpu and ctx is not None and dest_ptr):
                 raise ValueError("'ipc' needs a device destination, its raw pointer and the dsc context")
@@ -131,23 +132,37 @@ class ShardGather:
 
     # ---- HIP IPC: map every peer's destination into this process
     def _open_peers(self, dest_ptr):
+        """Every step that can fail on ONE rank only (export, opening a peer's handle) is followed by an agreement among all
+        ranks, so that a failure makes every rank raise together instead of leaving the others waiting in a collective."""
         from . import _bindings as B
         h = B._DscIpcHandle()
-        if B.dsc_ipc_export(self.ctx, dest_ptr, ctypes.byref(h)) != 0:
-            raise RuntimeError('dsc_ipc_export failed')
+        exported = B.dsc_ipc_export(self.ctx, dest_ptr, ctypes.byref(h)) == 0
         handles = [None] * self.world
-        self.dist.all_gather_object(handles, bytes(h.bytes))
-        self._mapped = [None] * self.world
+        self.dist.all_gather_object(handles, bytes(h.bytes) if exported else None)
+        failed = [p for p in range(self.world) if handles[p] is None]
+        if failed:
+            raise RuntimeError(f'dsc_ipc_export failed on rank(s) {failed}')
+        mapped = [None] * self.world
+        bad_peer = None
         for p in range(self.world):
             if p == self.rank:
-                self._mapped[p] = dest_ptr
+                mapped[p] = dest_ptr
                 continue
             hp = B._DscIpcHandle()
             ctypes.memmove(hp.bytes, handles[p], 64)
             m = B.dsc_ipc_open(self.ctx, ctypes.byref(hp))
             if not m:
-                raise RuntimeError(f'dsc_ipc_open of rank {p}\'s destination failed')
-            self._mapped[p] = m
+                bad_peer = p
+                break
+            mapped[p] = m
+        verdicts = [None] * self.world
+        self.dist.all_gather_object(verdicts, bad_peer)
+        if any(v is not None for v in verdicts):
+            for p, m in enumerate(mapped):
+                if p != self.rank and m:
+                    B.dsc_ipc_close(self.ctx, m)
+            raise RuntimeError('dsc_ipc_open failed: ' + ', '.join(f'rank {r} could not map rank {v}' for r, v in enumerate(verdicts) if v is not None))
+        self._mapped = mapped
         self._own_ptr = dest_ptr
 
     def _under_ctx_stream(self):
@@ -170,7 +185,7 @@ class ShardGather:
             for k in range(1, self.world):
                 p = (self.rank + k) % self.world          # staggered: at step k every rank targets a different peer
                 if B.dsc_peer_push(self.ctx, self._mapped[p] + off, self._own_ptr + off, nbytes, (k - 1) % lanes) != 0:
-                    raise RuntimeError(f'dsc_peer_push to rank {p} failed')
+                    self._failed = self._failed or f'dsc_peer_push to rank {p} failed'    # reported by finish(), on every rank
             return
         # 'p2p': one group of sends and receives per chunk
         dist = self.dist
@@ -200,13 +215,23 @@ class ShardGather:
             if self.method == 'ipc':
                 from . import _bindings as B
                 if B.dsc_peer_wait(self.ctx) != 0:
-                    raise RuntimeError('dsc_peer_wait failed')
+                    self._failed = self._failed or 'dsc_peer_wait failed'
         if self.on_gpu:
             import torch
             torch.cuda.synchronize()
-        if self.world > 1:
-            dist.barrier()
         self._pushed = 0
+        if self.world > 1:
+            if self.method == 'ipc':                          # the barrier doubles as the agreement on a one-sided failure
+                said = [None] * self.world
+                dist.all_gather_object(said, self._failed)
+                self._failed = None
+                if any(said):
+                    raise RuntimeError('; '.join(f'rank {r}: {m}' for r, m in enumerate(said) if m))
+            else:
+                dist.barrier()
+        elif self._failed:
+            msg, self._failed = self._failed, None
+            raise RuntimeError(msg)
 
     def close(self):
         if self._mapped is not None:
