@@ -40,17 +40,28 @@ template<typename R, int B, bool TWO> struct mid_cfg {
     // threads per workgroup.  f32: a thread needs ~100 VGPRs and 132-264 B of LDS, so two 512-thread groups (or three
     // of 256) share a CU and overlap each other's load / compute / store phases.  f64: twice the registers (one
     // 512-thread group or several smaller ones per CU) and twice the LDS, which decides the group size.
+#ifdef DSC_MID_PADDED_SHORT
+    static constexpr bool PACKED = false;
+#else
+    // Three-pass lines of 2048 points (B = 2): the last exchange keeps its 2-value rows UNPADDED and reads a row as one 8- /
+    // 16-byte access (conflict free, like the stride-1 writes) — the padded pitch 3 cost 50 % more LDS and left two 256-thread
+    // groups (two waves per SIMD) on a CU in f32; unpadded, two 512-thread groups fit (four per SIMD): irfft N = 4096 64.6 ->
+    // 71 %, fft 68 -> 73 %, fused filter 31 -> 38.6 %.  (B = 4 measured too: 1 % slower, stays padded.)
+    static constexpr bool PACKED = !TWO && B == 2;
+#endif
     static constexpr int NT = DP ? (TWO ? (B >= 32 ? 128 : 256) : (B >= 8 ? 512 : 128))
-                                 : (TWO ? 256 : B >= 32 ? 1024 : B >= 8 ? 512 : 256);
+                                 : (TWO ? 256 : B >= 32 ? 1024 : (B >= 8 || (PACKED && !DP)) ? 512 : 256);
     static constexpr int G = NT / T;                 // lines per workgroup
-    static constexpr int WAVES_PER_EU = DP ? 2 : (TWO ? 2 : B >= 8 ? 4 : 2);   // f32: <= 128 VGPRs where two 512-thread groups share a CU
+    static constexpr int WAVES_PER_EU = DP ? 2 : (TWO ? 2 : (B >= 8 || PACKED) ? 4 : 2);   // f32: <= 128 VGPRs where two 512-thread groups share a CU
     static constexpr int P1 = 33;                    // exchange-1 row pitch (values): odd
-    static constexpr int P2 = B + 1;                 // last-exchange row pitch
+    static constexpr int P2 = PACKED ? B : B + 1;    // last-exchange row pitch
     static constexpr int SP = L + 1;                 // staging pitch per line (bins 0 .. L)
     // values per line in the last exchange.  Two-pass: padded so that the stride is = B mod 64 — the lanes of a wave are
     // (line, j3) pairs and then hit 64 different banks (an unpadded 32 (B + 1) is = 32 mod 64: up to 16-way conflicts)
-    static constexpr int LSTRIDE = TWO ? 32 * (B + 1) + (((B - 32 - 32 * B) % 64) + 64) % 64 : 1024 * (B + 1);
-    static constexpr int PLANE = G * LSTRIDE;        // >= G*T*P1 (three-pass) and >= G*SP
+    static constexpr int LSTRIDE = TWO ? 32 * (B + 1) + (((B - 32 - 32 * B) % 64) + 64) % 64 : 1024 * P2;
+    static constexpr int PLANE_MIN = G * LSTRIDE;    // padded: >= G*T*P1 (three-pass) and >= G*SP; unpadded rows: take the largest
+    static constexpr int PLANE_X1 = TWO ? 0 : G * T * 33, PLANE_ST = G * (32 * T + 1);
+    static constexpr int PLANE = ((PLANE_MIN > PLANE_X1 ? (PLANE_MIN > PLANE_ST ? PLANE_MIN : PLANE_ST) : (PLANE_X1 > PLANE_ST ? PLANE_X1 : PLANE_ST)) + 3) & ~3;
     static constexpr int CPT = 32 / B;               // columns per thread in the last pass
     static constexpr int TABLE = TWO ? L : 1024;     // LDS twiddle table: W_L^m (two-pass) or W_1024^m
     static constexpr int TABLE_STRIDE = TWO ? 1 : B;
@@ -128,17 +139,33 @@ __device__ __forceinline__ void mid_passes(cpx<R> (&v)[32], R *plane, const cpx<
         for (int k2 = 0; k2 < 32; ++k2) wr[k2 * CS * P2] = u[brev(k2, 5)].x;
         lds_barrier();
 #pragma unroll
-        for (int i = 0; i < CPT; ++i)
+        for (int i = 0; i < CPT; ++i) {
+            if constexpr (cfg::PACKED) {
+                typedef R row_t __attribute__((ext_vector_type(B)));
+                const row_t q = *(const row_t *) (rd + i * T * P2);
 #pragma unroll
-            for (int m = 0; m < B; ++m) v[i * B + m].x = rd[i * T * P2 + m];
+                for (int m = 0; m < B; ++m) v[i * B + m].x = q[m];
+            } else {
+#pragma unroll
+                for (int m = 0; m < B; ++m) v[i * B + m].x = rd[i * T * P2 + m];
+            }
+        }
         lds_barrier();
 #pragma unroll
         for (int k2 = 0; k2 < 32; ++k2) wr[k2 * CS * P2] = u[brev(k2, 5)].y;
         lds_barrier();
 #pragma unroll
-        for (int i = 0; i < CPT; ++i)
+        for (int i = 0; i < CPT; ++i) {
+            if constexpr (cfg::PACKED) {
+                typedef R row_t __attribute__((ext_vector_type(B)));
+                const row_t q = *(const row_t *) (rd + i * T * P2);
 #pragma unroll
-            for (int m = 0; m < B; ++m) v[i * B + m].y = rd[i * T * P2 + m];
+                for (int m = 0; m < B; ++m) v[i * B + m].y = q[m];
+            } else {
+#pragma unroll
+                for (int m = 0; m < B; ++m) v[i * B + m].y = rd[i * T * P2 + m];
+            }
+        }
         lds_barrier();
     }
     // ---- last pass over j3: CPT DFTs of B points; v[i B + p] = bin k = (t + T i) + COLS brev(p)

@@ -106,6 +106,36 @@ __global__ __launch_bounds__(256) void row_copy_small(const f4 *__restrict__ in,
     }
 }
 
+
+// one f4 per thread with tiny workgroups, but in the ADDRESS ORDER of the row shape: consecutive workgroups take the same 4 KiB
+// piece of W consecutive rows, then the next piece of those rows ... (W = 1: plain address order)
+__global__ void copy_one_perm(const f4 *__restrict__ in, f4 *__restrict__ out, int W) {
+    const unsigned b = blockIdx.x;                          // 64 pieces of 4 KiB per 256 KiB row
+    const unsigned per_window = (unsigned) W * 64;
+    const unsigned window = b / per_window, in_w = b % per_window;
+    const unsigned row = window * W + in_w % W, piece = in_w / W;
+    const size_t i = ((size_t) row * 64 + piece) * 256 + threadIdx.x;
+    out[i] = in[i];
+}
+
+
+// persistent row copy with a row pitch (in f4) and two row orders: mode 0 row = block + k * grid (256 consecutive rows open),
+// mode 1 each block walks its own contiguous band of rows (open rows are rows / grid apart)
+__global__ __launch_bounds__(1024) void row_copy_pitch(const f4 *__restrict__ in, f4 *__restrict__ out, int rows, size_t in_pitch, size_t out_pitch, int mode) {
+    const int t = threadIdx.x;
+    const int per = rows / gridDim.x;
+    for (int k = 0; k < per; ++k) {
+        const int row = mode == 0 ? blockIdx.x + k * gridDim.x : blockIdx.x * per + k;
+        const f4 *src = in + (size_t) row * in_pitch;
+        f4 *dst = out + (size_t) row * out_pitch;
+        f4 v[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) v[p] = src[p * 1024 + t];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) dst[p * 1024 + t] = v[p];
+    }
+}
+
 // non-persistent: one workgroup per row (dispatch order = address order)
 template<int MODE>
 __global__ __launch_bounds__(1024) void row_copy_np(const f4 *__restrict__ in, f4 *__restrict__ out, float *sink) {
@@ -193,6 +223,24 @@ int main() {
     rep("row copy 2048 x 256 threads, depth 4", timeit([&] { hipLaunchKernelGGL((row_copy_small<4>), dim3(2048), dim3(256), 0, 0, x, y, rows); }), 2.0 * bytes);
     rep("row copy 2048 x 256 threads, depth 1", timeit([&] { hipLaunchKernelGGL((row_copy_small<1>), dim3(2048), dim3(256), 0, 0, x, y, rows); }), 2.0 * bytes);
     rep("row copy 8192 x 256 threads (one per row), depth 4", timeit([&] { hipLaunchKernelGGL((row_copy_small<4>), dim3(8192), dim3(256), 0, 0, x, y, rows); }), 2.0 * bytes);
+
+    for (int W : {1, 4, 16, 64, 256, 1024}) {
+        snprintf(name, sizeof name, "one f4 per thread, copy, row-shaped address order over %d rows", W);
+        rep(name, timeit([&] { hipLaunchKernelGGL(copy_one_perm, dim3((unsigned) (n / 256)), dim3(256), 0, 0, x, y, W); }), 2.0 * bytes);
+    }
+
+    {
+        const int prow = 6144;                              // fewer rows so that padded pitches fit the 2 GiB buffers
+        const double pb = 2.0 * prow * 262144.0;
+        for (size_t pad : {(size_t) 0, (size_t) 8, (size_t) 64, (size_t) 256, (size_t) 1024, (size_t) 4096, (size_t) 5120}) {
+            snprintf(name, sizeof name, "row copy, in and out pitch 256 KiB + %zu B", pad * 16);
+            rep(name, timeit([&] { hipLaunchKernelGGL(row_copy_pitch, dim3(256), dim3(1024), 0, 0, x, y, prow, 16384 + pad, 16384 + pad, 0); }), pb);
+        }
+        rep("row copy, in pitch 256 KiB, out pitch 256 KiB + 16 KiB", timeit([&] { hipLaunchKernelGGL(row_copy_pitch, dim3(256), dim3(1024), 0, 0, x, y, prow, 16384, 16384 + 1024, 0); }), pb);
+        rep("row copy, in pitch 256 KiB + 16 KiB, out pitch 256 KiB", timeit([&] { hipLaunchKernelGGL(row_copy_pitch, dim3(256), dim3(1024), 0, 0, x, y, prow, 16384 + 1024, 16384, 0); }), pb);
+        rep("row copy, pitch 256 KiB, each block its own band of rows", timeit([&] { hipLaunchKernelGGL(row_copy_pitch, dim3(256), dim3(1024), 0, 0, x, y, prow, 16384, 16384, 1); }), pb);
+        rep("row copy, pitch 256 KiB + 16 KiB, each block its own band of rows", timeit([&] { hipLaunchKernelGGL(row_copy_pitch, dim3(256), dim3(1024), 0, 0, x, y, prow, 16384 + 1024, 16384 + 1024, 1); }), pb);
+    }
     rep("one workgroup per row (8192 x 1024), copy", timeit([&] { hipLaunchKernelGGL((row_copy_np<0>), dim3(rows), dim3(1024), 0, 0, x, y, sink); }), 2.0 * bytes);
     rep("one workgroup per row (8192 x 1024), read", timeit([&] { hipLaunchKernelGGL((row_copy_np<1>), dim3(rows), dim3(1024), 0, 0, x, y, sink); }), 1.0 * bytes);
     rep("one workgroup per row (8192 x 1024), write", timeit([&] { hipLaunchKernelGGL((row_copy_np<2>), dim3(rows), dim3(1024), 0, 0, x, y, sink); }), 1.0 * bytes);
