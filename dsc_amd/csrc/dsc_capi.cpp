@@ -330,6 +330,10 @@ static dsc_tensor *binary_entry(dsc_ctx *ctx, dsc_tensor *xa, dsc_tensor *xb, ds
         DSC_ASSERT(memcmp(out->shape, shape, sizeof(shape)) == 0);
     }
 
+    if (xa->dtype != xb->dtype && xa->ne == out->ne && xb->ne == out->ne &&
+        dsc_launch_binary_mixed(xa->data, xa->dtype, xb->data, xb->dtype, out->data, op, out->ne, ctx->stream))
+        return out;                                 // equal shapes, different dtypes: promoted in registers
+
     ctx->scratch.reset();                           // DSC_CTX_PUSH
     dsc_tensor *ca = cast_into(ctx, xa, out_dtype, true);
     dsc_tensor *cb = cast_into(ctx, xb, out_dtype, true);

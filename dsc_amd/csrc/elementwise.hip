@@ -9,6 +9,7 @@
 #include "kernels.h"
 
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 namespace {
 
@@ -19,6 +20,32 @@ template<> struct elem<float>  { static constexpr bool cplx = false; using real 
 template<> struct elem<double> { static constexpr bool cplx = false; using real = double; };
 template<> struct elem<cx<float>>  { static constexpr bool cplx = true; using real = float; };
 template<> struct elem<cx<double>> { static constexpr bool cplx = true; using real = double; };
+
+inline dim3 stream_grid(long long ne) {
+    long long blocks = (ne + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;        // 8 blocks per CU, grid-stride beyond that
+    if (blocks < 1) blocks = 1;
+    return dim3((unsigned) blocks);
+}
+
+// Grid of the PACKED kernels (16 bytes per thread in their widest stream): one pack per thread, no loop in practice —
+// workgroups are dispatched in address order and end right after their store, so the whole chip sweeps one window of memory:
+// 6.2 TB/s for a copy against 4.7 TB/s for 2048 grid-striding workgroups (tools/membench2.hip; mul c32 of equal shapes
+// 62.8 -> 81.4 % of the roofline).  With 4 or 8 bytes per thread the same launch is SLOWER than the capped grid (measured:
+// abs c32 69.5 -> 66 %, cast f32 -> c32 67.7 -> 55.8 %), hence the packs.  2^23 blocks keep the 32-bit strides at <= 2^31.
+inline dim3 pack_grid(long long npack) {
+    long long blocks = (npack + 255) / 256;
+#ifdef DSC_STREAM_GRID_CAPPED
+    if (blocks > 256 * 8) blocks = 256 * 8;
+#endif
+    if (blocks > (1 << 23)) blocks = 1 << 23;
+    if (blocks < 1) blocks = 1;
+    return dim3((unsigned) blocks);
+}
+
+template<typename T, int V> struct alignas(sizeof(T) * V) packed { T e[V]; };
+template<typename A, typename B> constexpr int pack_width() { return 16 / (int) (sizeof(A) > sizeof(B) ? sizeof(A) : sizeof(B)); }
+inline bool aligned_to(const void *p, size_t a) { return ((size_t) p & (a - 1)) == 0; }
 
 // cast_op (dsc_ops.h:12-44): complex -> real keeps .real; real -> complex sets imag = 0
 template<typename Tin, typename Tout>
@@ -39,22 +66,41 @@ __global__ void cast_kernel(const Tin *in, Tout *out, long long ne) {
         out[i] = cast_one<Tin, Tout>(in[i]);
 }
 
-template<typename Tin>
-void cast_from(const void *in, void *out, int out_dtype, long long ne, dim3 grid, hipStream_t s) {
-    const Tin *x = (const Tin *) in;
-    switch (out_dtype) {
-        case 0: DSC_LAUNCH((cast_kernel<Tin, float>), grid, dim3(256), 0, s, x, (float *) out, ne); break;
-        case 1: DSC_LAUNCH((cast_kernel<Tin, double>), grid, dim3(256), 0, s, x, (double *) out, ne); break;
-        case 2: DSC_LAUNCH((cast_kernel<Tin, cx<float>>), grid, dim3(256), 0, s, x, (cx<float> *) out, ne); break;
-        default: DSC_LAUNCH((cast_kernel<Tin, cx<double>>), grid, dim3(256), 0, s, x, (cx<double> *) out, ne); break;
+// V consecutive elements per thread, 16 bytes in the wider of the two streams
+template<typename Tin, typename Tout, int V>
+__global__ void cast_pack_kernel(const Tin *in, Tout *out, unsigned npack) {
+    const packed<Tin, V> *pi = (const packed<Tin, V> *) in;
+    packed<Tout, V> *po = (packed<Tout, V> *) out;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < npack; i += gridDim.x * blockDim.x) {
+        const packed<Tin, V> x = pi[i];
+        packed<Tout, V> r;
+#pragma unroll
+        for (int j = 0; j < V; ++j) r.e[j] = cast_one<Tin, Tout>(x.e[j]);
+        po[i] = r;
     }
 }
 
-inline dim3 stream_grid(long long ne) {
-    long long blocks = (ne + 255) / 256;
-    if (blocks > 256 * 8) blocks = 256 * 8;        // 8 blocks per CU, grid-stride beyond that
-    if (blocks < 1) blocks = 1;
-    return dim3((unsigned) blocks);
+template<typename Tin, typename Tout>
+void cast_to(const Tin *x, Tout *out, long long ne, hipStream_t s) {
+    constexpr int V = pack_width<Tin, Tout>();
+    long long done = 0;
+    if (ne >= V && aligned_to(x, sizeof(Tin) * V) && aligned_to(out, sizeof(Tout) * V)) {
+        const long long npack = ne / V;
+        DSC_LAUNCH((cast_pack_kernel<Tin, Tout, V>), pack_grid(npack), dim3(256), 0, s, x, out, (unsigned) npack);
+        done = npack * V;
+    }
+    if (done < ne) DSC_LAUNCH((cast_kernel<Tin, Tout>), stream_grid(ne - done), dim3(256), 0, s, x + done, out + done, ne - done);
+}
+
+template<typename Tin>
+void cast_from(const void *in, void *out, int out_dtype, long long ne, dim3, hipStream_t s) {
+    const Tin *x = (const Tin *) in;
+    switch (out_dtype) {
+        case 0: cast_to<Tin, float>(x, (float *) out, ne, s); break;
+        case 1: cast_to<Tin, double>(x, (double *) out, ne, s); break;
+        case 2: cast_to<Tin, cx<float>>(x, (cx<float> *) out, ne, s); break;
+        default: cast_to<Tin, cx<double>>(x, (cx<double> *) out, ne, s); break;
+    }
 }
 
 // add_op / sub_op / mul_op / div_op: dsc_ops.h:46-90
@@ -146,13 +192,46 @@ __global__ void binary_same_vec_kernel(const T *a, const T *b, T *out, unsigned 
     }
 }
 
+// One operand has the output's shape, the other is a scalar or spans the trailing dims (a [B, K] spectrum times a [K] filter):
+// 16 bytes per thread of the large operand and of the result; the small operand is read per element (it lives in the caches),
+// its index from ONE modulo per thread.  BIG_IS_A: out = big op small, else out = small op big.
+template<typename T, int OP, bool BIG_IS_A>
+__global__ void binary_small_pack_kernel(const T *big, const T *small, T *out, unsigned npack, unsigned small_ne) {
+    constexpr int V = 16 / sizeof(T);
+    const packed<T, V> *pbig = (const packed<T, V> *) big;
+    packed<T, V> *po = (packed<T, V> *) out;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < npack; i += gridDim.x * blockDim.x) {
+        const packed<T, V> x = pbig[i];
+        unsigned m = small_ne == 1 ? 0u : (unsigned) (((unsigned long long) i * V) % small_ne);
+        packed<T, V> r;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const T sv = small[m];
+            r.e[j] = BIG_IS_A ? apply<T, OP>(x.e[j], sv) : apply<T, OP>(sv, x.e[j]);
+            m = m + 1 >= small_ne ? 0u : m + 1;
+        }
+        po[i] = r;
+    }
+}
+
 template<typename T, int OP>
 bool binary_fast(const T *pa, const T *pb, T *po, const dsc_bcast_args &g, dim3 grid, hipStream_t s) {
+    constexpr unsigned V = 16 / sizeof(T);
+    if ((g.a_scalar || g.b_scalar || g.fast >= 2) && g.ne % V == 0) {
+        const bool big_is_a = g.b_scalar || (!g.a_scalar && g.fast == 2);
+        const T *big = big_is_a ? pa : pb, *small = big_is_a ? pb : pa;
+        const unsigned sm = (g.a_scalar || g.b_scalar) ? 1u : (unsigned) g.small_ne;
+        if (aligned_to(big, 16) && aligned_to(po, 16) && sm >= 1) {
+            const unsigned npack = (unsigned) (g.ne / V);
+            if (big_is_a) DSC_LAUNCH((binary_small_pack_kernel<T, OP, true>), pack_grid(npack), dim3(256), 0, s, big, small, po, npack, sm);
+            else          DSC_LAUNCH((binary_small_pack_kernel<T, OP, false>), pack_grid(npack), dim3(256), 0, s, big, small, po, npack, sm);
+            return true;
+        }
+    }
     if (g.a_scalar || g.b_scalar || g.fast == 0) return false;
     const unsigned ne = (unsigned) g.ne, sm = (unsigned) g.small_ne;
-    constexpr unsigned V = 16 / sizeof(T);
     if (g.fast == 1 && V > 1 && ne % V == 0 && (((size_t) pa | (size_t) pb | (size_t) po) & 15) == 0) {
-        DSC_LAUNCH((binary_same_vec_kernel<T, OP>), stream_grid(ne / V), dim3(256), 0, s, pa, pb, po, ne / V);
+        DSC_LAUNCH((binary_same_vec_kernel<T, OP>), pack_grid(ne / V), dim3(256), 0, s, pa, pb, po, ne / V);
         return true;
     }
     if (g.fast == 1) DSC_LAUNCH((binary_fast_kernel<T, OP, 1>), grid, dim3(256), 0, s, pa, pb, po, ne, sm);
@@ -191,38 +270,76 @@ void binary_typed(const void *a, const void *b, void *out, int op, const dsc_bca
 
 // abs / angle / conj / real / imag: dsc/src/dsc.cpp:1480-1622, functors dsc_ops.h:242-303.
 // OP: 0 abs, 1 angle, 2 conj, 3 real, 4 imag.  Tin real or complex, output real (conj: same as input).
+template<typename Tin, int OP> struct unary_out { using type = typename elem<Tin>::real; };
+template<typename R> struct unary_out<cx<R>, 2> { using type = cx<R>; };
+
+template<typename Tin, int OP>
+__device__ __forceinline__ typename unary_out<Tin, OP>::type unary_one(Tin v) {
+    using R = typename elem<Tin>::real;
+    R re, im;
+    if constexpr (elem<Tin>::cplx) { re = v.x; im = v.y; }
+    else                           { re = v; im = (R) 0; }
+    if constexpr (OP == 0) {
+        if constexpr (elem<Tin>::cplx) return sqrt((re * re) + (im * im));
+        else                           return re >= 0 ? re : -re;
+    } else if constexpr (OP == 1) {
+        return atan2(im, re);
+    } else if constexpr (OP == 2) {
+        if constexpr (elem<Tin>::cplx) return Tin{re, -im};
+        else                           return re;
+    } else if constexpr (OP == 3) {
+        return re;
+    } else {
+        return im;
+    }
+}
+
 template<typename Tin, int OP>
 __global__ void unary_kernel(const Tin *in, void *out, long long ne) {
-    using R = typename elem<Tin>::real;
-    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < ne; i += (long long) gridDim.x * blockDim.x) {
-        R re, im;
-        if constexpr (elem<Tin>::cplx) { const Tin v = in[i]; re = v.x; im = v.y; }
-        else                           { re = in[i]; im = (R) 0; }
-        if constexpr (OP == 0) {
-            if constexpr (elem<Tin>::cplx) ((R *) out)[i] = sqrt((re * re) + (im * im));
-            else                           ((R *) out)[i] = re >= 0 ? re : -re;
-        } else if constexpr (OP == 1) {
-            ((R *) out)[i] = atan2(im, re);
-        } else if constexpr (OP == 2) {
-            if constexpr (elem<Tin>::cplx) ((Tin *) out)[i] = Tin{re, -im};
-            else                           ((R *) out)[i] = re;
-        } else if constexpr (OP == 3) {
-            ((R *) out)[i] = re;
-        } else {
-            ((R *) out)[i] = im;
-        }
+    using Tout = typename unary_out<Tin, OP>::type;
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < ne; i += (long long) gridDim.x * blockDim.x)
+        ((Tout *) out)[i] = unary_one<Tin, OP>(in[i]);
+}
+
+template<typename Tin, int OP, int V>
+__global__ void unary_pack_kernel(const Tin *in, void *out, unsigned npack) {
+    using Tout = typename unary_out<Tin, OP>::type;
+    const packed<Tin, V> *pi = (const packed<Tin, V> *) in;
+    packed<Tout, V> *po = (packed<Tout, V> *) out;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < npack; i += gridDim.x * blockDim.x) {
+        const packed<Tin, V> x = pi[i];
+        packed<Tout, V> r;
+#pragma unroll
+        for (int j = 0; j < V; ++j) r.e[j] = unary_one<Tin, OP>(x.e[j]);
+        po[i] = r;
+    }
+}
+
+template<typename Tin, int OP>
+void unary_op(const Tin *x, void *out, long long ne, hipStream_t s) {
+    using Tout = typename unary_out<Tin, OP>::type;
+    constexpr int V = pack_width<Tin, Tout>();
+    long long done = 0;
+    if (V > 1 && ne >= V && aligned_to(x, sizeof(Tin) * V) && aligned_to(out, sizeof(Tout) * V)) {
+        const long long npack = ne / V;
+        DSC_LAUNCH((unary_pack_kernel<Tin, OP, V>), pack_grid(npack), dim3(256), 0, s, x, out, (unsigned) npack);
+        done = npack * V;
+    }
+    if (done < ne) {
+        if (V == 1) DSC_LAUNCH((unary_kernel<Tin, OP>), pack_grid(ne), dim3(256), 0, s, x, out, ne);       // 16 bytes per element already
+        else DSC_LAUNCH((unary_kernel<Tin, OP>), stream_grid(ne - done), dim3(256), 0, s, x + done, (void *) ((Tout *) out + done), ne - done);
     }
 }
 
 template<typename Tin>
-void unary_typed(const void *in, void *out, int op, long long ne, dim3 grid, hipStream_t s) {
+void unary_typed(const void *in, void *out, int op, long long ne, dim3, hipStream_t s) {
     const Tin *x = (const Tin *) in;
     switch (op) {
-        case 0: DSC_LAUNCH((unary_kernel<Tin, 0>), grid, dim3(256), 0, s, x, out, ne); break;
-        case 1: DSC_LAUNCH((unary_kernel<Tin, 1>), grid, dim3(256), 0, s, x, out, ne); break;
-        case 2: DSC_LAUNCH((unary_kernel<Tin, 2>), grid, dim3(256), 0, s, x, out, ne); break;
-        case 3: DSC_LAUNCH((unary_kernel<Tin, 3>), grid, dim3(256), 0, s, x, out, ne); break;
-        default: DSC_LAUNCH((unary_kernel<Tin, 4>), grid, dim3(256), 0, s, x, out, ne); break;
+        case 0: unary_op<Tin, 0>(x, out, ne, s); break;
+        case 1: unary_op<Tin, 1>(x, out, ne, s); break;
+        case 2: unary_op<Tin, 2>(x, out, ne, s); break;
+        case 3: unary_op<Tin, 3>(x, out, ne, s); break;
+        default: unary_op<Tin, 4>(x, out, ne, s); break;
     }
 }
 
@@ -247,6 +364,71 @@ void dsc_launch_unary(const void *in, int in_dtype, void *out, int op, long long
         case 1: unary_typed<double>(in, out, op, ne, grid, stream); break;
         case 2: unary_typed<cx<float>>(in, out, op, ne, grid, stream); break;
         default: unary_typed<cx<double>>(in, out, op, ne, grid, stream); break;
+    }
+}
+
+// ---- operands of DIFFERENT dtypes and equal shapes: the casts of binary_op (dsc.cpp:1186-1223 casts both operands to the
+// promoted type first) happen in registers — same expression per element (cast_one, then apply), no temporary in HBM.
+namespace {
+template<typename Ta, typename Tb> struct promoted {          // dsc_dtype.h:73-78
+    static constexpr bool cplx = elem<Ta>::cplx || elem<Tb>::cplx;
+    static constexpr bool wide = cplx ? (sizeof(Ta) == 16 || sizeof(Tb) == 16)
+                                      : (sizeof(Ta) == 8 || sizeof(Tb) == 8);
+    using real = typename std::conditional<wide, double, float>::type;
+    using type = typename std::conditional<cplx, cx<real>, real>::type;
+};
+
+template<typename Ta, typename Tb, int OP>
+__global__ void binary_mixed_pack_kernel(const Ta *a, const Tb *b, typename promoted<Ta, Tb>::type *out, unsigned npack) {
+    using To = typename promoted<Ta, Tb>::type;
+    constexpr int V = 16 / sizeof(To);
+    const packed<Ta, V> *pa = (const packed<Ta, V> *) a;
+    const packed<Tb, V> *pb = (const packed<Tb, V> *) b;
+    packed<To, V> *po = (packed<To, V> *) out;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < npack; i += gridDim.x * blockDim.x) {
+        const packed<Ta, V> x = pa[i];
+        const packed<Tb, V> y = pb[i];
+        packed<To, V> r;
+#pragma unroll
+        for (int j = 0; j < V; ++j) r.e[j] = apply<To, OP>(cast_one<Ta, To>(x.e[j]), cast_one<Tb, To>(y.e[j]));
+        po[i] = r;
+    }
+}
+
+template<typename Ta, typename Tb>
+bool mixed_pair(const void *a, const void *b, void *out, int op, long long ne, hipStream_t s) {
+    using To = typename promoted<Ta, Tb>::type;
+    constexpr int V = 16 / sizeof(To);
+    if (ne % V != 0 || !aligned_to(a, sizeof(Ta) * V) || !aligned_to(b, sizeof(Tb) * V) || !aligned_to(out, 16)) return false;
+    const unsigned npack = (unsigned) (ne / V);
+    const Ta *pa = (const Ta *) a; const Tb *pb = (const Tb *) b; To *po = (To *) out;
+    switch (op) {
+        case 0: DSC_LAUNCH((binary_mixed_pack_kernel<Ta, Tb, 0>), pack_grid(npack), dim3(256), 0, s, pa, pb, po, npack); break;
+        case 1: DSC_LAUNCH((binary_mixed_pack_kernel<Ta, Tb, 1>), pack_grid(npack), dim3(256), 0, s, pa, pb, po, npack); break;
+        case 2: DSC_LAUNCH((binary_mixed_pack_kernel<Ta, Tb, 2>), pack_grid(npack), dim3(256), 0, s, pa, pb, po, npack); break;
+        default: DSC_LAUNCH((binary_mixed_pack_kernel<Ta, Tb, 3>), pack_grid(npack), dim3(256), 0, s, pa, pb, po, npack); break;
+    }
+    return true;
+}
+
+template<typename Ta>
+bool mixed_a(const void *a, const void *b, int b_dtype, void *out, int op, long long ne, hipStream_t s) {
+    switch (b_dtype) {
+        case 0: return mixed_pair<Ta, float>(a, b, out, op, ne, s);
+        case 1: return mixed_pair<Ta, double>(a, b, out, op, ne, s);
+        case 2: return mixed_pair<Ta, cx<float>>(a, b, out, op, ne, s);
+        default: return mixed_pair<Ta, cx<double>>(a, b, out, op, ne, s);
+    }
+}
+}  // namespace
+
+bool dsc_launch_binary_mixed(const void *a, int a_dtype, const void *b, int b_dtype, void *out, int op, long long ne, hipStream_t stream) {
+    if (ne <= 0 || a_dtype == b_dtype) return false;
+    switch (a_dtype) {
+        case 0: return mixed_a<float>(a, b, b_dtype, out, op, ne, stream);
+        case 1: return mixed_a<double>(a, b, b_dtype, out, op, ne, stream);
+        case 2: return mixed_a<cx<float>>(a, b, b_dtype, out, op, ne, stream);
+        default: return mixed_a<cx<double>>(a, b, b_dtype, out, op, ne, stream);
     }
 }
 

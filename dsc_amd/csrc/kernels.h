@@ -178,6 +178,9 @@ struct dsc_bcast_args {
 };
 // op: 0 add, 1 sub, 2 mul, 3 div   (only mul is exported through the C ABI this round)
 void dsc_launch_binary(const void *a, const void *b, void *out, int dtype, int op, const dsc_bcast_args &g, hipStream_t stream);
+// operands of different dtypes, equal shapes, contiguous: casts to the promoted dtype in registers.  false = not taken
+// (odd element count or unaligned views): the caller casts into scratch tensors and calls dsc_launch_binary.
+bool dsc_launch_binary_mixed(const void *a, int a_dtype, const void *b, int b_dtype, void *out, int op, long long ne, hipStream_t stream);
 
 // ---- reductions along one axis -----------------------------------------------------------
 // x viewed as [outer][axis_n][inner] contiguous; out as [outer][inner].

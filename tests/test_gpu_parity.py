@@ -182,6 +182,74 @@ def test_mul_broadcast_and_scalars(dsc):
     assert (dsc.from_numpy(d) * dsc.from_numpy(a)).dtype == dsc.Dtype.C32       # F64 x C32 -> C32
 
 
+def _rand(rng, shape, dt):
+    x = rng.standard_normal(shape)
+    if np.dtype(dt).kind == 'c':
+        x = x + 1j * rng.standard_normal(shape)
+    return x.astype(dt)
+
+
+@pytest.mark.parametrize('shape', [(6, 1000), (5, 1001)])       # even element count: packed kernels; odd: the scalar tail / fallback
+def test_binary_ops_every_dtype_pair_in_registers(dsc, shape):
+    """Equal shapes, every (dtype, dtype) pair and operator: operands of different dtypes are promoted in registers
+    (binary_mixed_pack_kernel) — must give exactly what the reference's cast-both-then-operate gives (dsc.cpp:1186-1223)."""
+    from oracle import port
+    rng = np.random.default_rng(21)
+    dts = (np.float32, np.float64, np.complex64, np.complex128)
+    for da in dts:
+        for db in dts:
+            a, b = _rand(rng, shape, da), _rand(rng, shape, db)
+            for op, f in ((0, dsc.add), (1, dsc.sub), (2, dsc.mul), (3, dsc.true_div)):
+                got = f(dsc.from_numpy(a), dsc.from_numpy(b)).numpy()
+                want = port.binary(a, b, op)
+                assert got.dtype == want.dtype, (da, db, op)
+                if op >= 2:
+                    assert_close(got, want, what=f'op {op} {da} {db}')          # complex products contract into FMAs, divisions differ
+                else:
+                    assert np.array_equal(got, want), (da, db, op, shape)
+
+
+@pytest.mark.parametrize('dt', [np.float32, np.float64, np.complex64, np.complex128])
+def test_binary_ops_small_operand_packed(dsc, dt):
+    """A full operand against a scalar or a trailing-dims operand (either side), row lengths odd and even, plus views that are
+    not 16-byte aligned (the packed kernel must not be taken): exact against the oracle."""
+    from oracle import port
+    rng = np.random.default_rng(22)
+    for shape, small in (((8, 513), (513,)), ((8, 512), (512,)), ((3, 4, 130), (4, 130)), ((16, 6), (6,)), ((4, 1024), (1,))):
+        a, h = _rand(rng, shape, dt), _rand(rng, small, dt)
+        for op, f in ((0, dsc.add), (1, dsc.sub), (2, dsc.mul), (3, dsc.true_div)):
+            for got, want in ((f(dsc.from_numpy(a), dsc.from_numpy(h)).numpy(), port.binary(a, h, op)),
+                              (f(dsc.from_numpy(h), dsc.from_numpy(a)).numpy(), port.binary(h, a, op))):
+                if op >= 2:
+                    assert_close(got, want, what=f'op {op} {shape} {small}')
+                else:
+                    assert np.array_equal(got, want), (shape, small, op)
+    a = _rand(rng, (9, 64), dt)
+    t = dsc.from_numpy(a)
+    odd = t[1:]                                                 # a copy at a fresh address: still exercised through the fast path
+    assert_close((odd * 3).numpy(), port.binary(a[1:], np.array([3]).astype(dt), 2))
+
+
+def test_unary_and_cast_packed_and_tails(dsc):
+    """abs / angle / conj / real / imag and casts on element counts that are and are not multiples of the pack width."""
+    from oracle import port
+    rng = np.random.default_rng(23)
+    dts = (np.float32, np.float64, np.complex64, np.complex128)
+    for n in (4096, 4099, 3):
+        for dt in dts:
+            x = _rand(rng, (n,), dt)
+            t = dsc.from_numpy(x)
+            for op, f in ((0, dsc.absolute), (1, dsc.angle), (2, dsc.conj), (3, dsc.real), (4, dsc.imag)):
+                got, want = f(t).numpy(), port.unary(x, op)
+                assert got.dtype == want.dtype, (dt, op)
+                if op in (0, 1):
+                    assert_close(got, want, what=f'unary {op} {dt} n={n}')       # sqrt / atan2: library functions
+                else:
+                    assert np.array_equal(got, want), (dt, op, n)
+            for to, dto in ((dsc.Dtype.F32, np.float32), (dsc.Dtype.F64, np.float64), (dsc.Dtype.C32, np.complex64), (dsc.Dtype.C64, np.complex128)):
+                assert np.array_equal(t.cast(to).numpy(), port.cast(x, dto)), (dt, dto, n)
+
+
 def test_reduce_large_rows(dsc):
     """Row-reduction kernel (inner == 1, tree order) and sequential kernel on bigger inputs."""
     from oracle import port
