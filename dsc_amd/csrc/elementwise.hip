@@ -240,6 +240,60 @@ bool binary_fast(const T *pa, const T *pb, T *po, const dsc_bcast_args &g, dim3 
     return true;
 }
 
+// General broadcast, 16 bytes of the result per thread: along the innermost axis an operand either advances with the result
+// (one 16-byte load) or is broadcast (one element); the outer indices come from one division chain per thread.  A block is no
+// longer tied to one innermost row, so short rows (512 floats) fill their workgroups too.
+template<typename T, int OP>
+__global__ void binary_bcast_pack_kernel(const T *a, const T *b, T *out, const dsc_bcast_args g, unsigned packs_per_row, unsigned npack) {
+    constexpr int V = 16 / sizeof(T);
+    packed<T, V> *po = (packed<T, V> *) out;
+    const unsigned s2 = (unsigned) g.out_shape[2], s1 = (unsigned) g.out_shape[1];
+    for (unsigned p = blockIdx.x * blockDim.x + threadIdx.x; p < npack; p += gridDim.x * blockDim.x) {
+        const unsigned row = p / packs_per_row, c = (p - row * packs_per_row) * V;
+        const unsigned t = row / s2, i2 = row - t * s2;
+        const unsigned i0 = t / s1, i1 = t - i0 * s1;
+        const T *ra = a + ((long long) i0 * g.a_stride[0] + (long long) i1 * g.a_stride[1] + (long long) i2 * g.a_stride[2]);
+        const T *rb = b + ((long long) i0 * g.b_stride[0] + (long long) i1 * g.b_stride[1] + (long long) i2 * g.b_stride[2]);
+        packed<T, V> x, y, r;
+        if (g.a_stride[3]) x = *(const packed<T, V> *) (ra + c);
+        else {
+            const T v = ra[0];
+#pragma unroll
+            for (int j = 0; j < V; ++j) x.e[j] = v;
+        }
+        if (g.b_stride[3]) y = *(const packed<T, V> *) (rb + c);
+        else {
+            const T v = rb[0];
+#pragma unroll
+            for (int j = 0; j < V; ++j) y.e[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) r.e[j] = apply<T, OP>(x.e[j], y.e[j]);
+        po[p] = r;
+    }
+}
+
+template<typename T>
+bool binary_bcast_pack(const T *pa, const T *pb, T *po, int op, const dsc_bcast_args &g, hipStream_t s) {
+    constexpr int V = 16 / sizeof(T);
+    if (g.a_scalar || g.b_scalar || g.out_shape[3] % V != 0 || !aligned_to(po, 16) || g.ne / V >= (1LL << 32)) return false;
+    auto fits = [&](const T *p, const int *st) {
+        if (st[3] == 0) return true;
+        if (st[3] != 1 || !aligned_to(p, 16)) return false;
+        for (int k = 0; k < 3; ++k) if (st[k] % V != 0) return false;
+        return true;
+    };
+    if (!fits(pa, g.a_stride) || !fits(pb, g.b_stride)) return false;
+    const unsigned ppr = (unsigned) (g.out_shape[3] / V), npack = (unsigned) (g.ne / V);
+    switch (op) {
+        case 0: DSC_LAUNCH((binary_bcast_pack_kernel<T, 0>), pack_grid(npack), dim3(256), 0, s, pa, pb, po, g, ppr, npack); break;
+        case 1: DSC_LAUNCH((binary_bcast_pack_kernel<T, 1>), pack_grid(npack), dim3(256), 0, s, pa, pb, po, g, ppr, npack); break;
+        case 2: DSC_LAUNCH((binary_bcast_pack_kernel<T, 2>), pack_grid(npack), dim3(256), 0, s, pa, pb, po, g, ppr, npack); break;
+        default: DSC_LAUNCH((binary_bcast_pack_kernel<T, 3>), pack_grid(npack), dim3(256), 0, s, pa, pb, po, g, ppr, npack); break;
+    }
+    return true;
+}
+
 template<typename T>
 void binary_typed(const void *a, const void *b, void *out, int op, const dsc_bcast_args &g, dim3 grid, hipStream_t s) {
     const T *pa = (const T *) a, *pb = (const T *) b;
@@ -248,6 +302,7 @@ void binary_typed(const void *a, const void *b, void *out, int op, const dsc_bca
     if (op == 1 && binary_fast<T, 1>(pa, pb, po, g, grid, s)) return;
     if (op == 2 && binary_fast<T, 2>(pa, pb, po, g, grid, s)) return;
     if (op == 3 && binary_fast<T, 3>(pa, pb, po, g, grid, s)) return;
+    if (binary_bcast_pack<T>(pa, pb, po, op, g, s)) return;
     const long long rows = g.out_shape[3] > 0 ? g.ne / g.out_shape[3] : 0;
     const unsigned chunks = (unsigned) ((g.out_shape[3] + 1023) / 1024);
     if (!g.a_scalar && !g.b_scalar && g.out_shape[3] >= 64 && rows * chunks < (1LL << 31)) {
@@ -450,6 +505,10 @@ void dsc_launch_binary(const void *a, const void *b, void *out, int dtype, int o
 namespace {
 
 struct alignas(16) b16 { unsigned long long a, b; };
+// elements per thread of region_rows_kernel: ONE 16-byte pack (the launch then sweeps memory in address order and every
+// workgroup ends right after its store: x[:, :60000] 67 -> 73.5 % of the roofline), four of the narrower elements (with one
+// per thread the strided x[:, ::2] drops from 49 to 35 %)
+template<typename E> constexpr int region_u() { return sizeof(E) == 16 ? 1 : 4; }
 
 template<typename E, bool SCATTER>
 __global__ void region_rows_kernel(const E *src, E *dst, const dsc_region r, unsigned chunks_per_row, long long dense_ne) {
@@ -461,9 +520,10 @@ __global__ void region_rows_kernel(const E *src, E *dst, const dsc_region r, uns
     const long long i0 = (long long) (i01 / r.count[1]), i1 = (long long) (i01 - (unsigned long long) i0 * r.count[1]);
     const long long base = r.base + i0 * r.stride[0] + i1 * r.stride[1] + i2 * r.stride[2];
     const long long dense0 = (long long) row * r.count[3];
+    constexpr int U = region_u<E>();
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {                                   // four elements per thread: 1024 per block
-        const int c = chunk * 1024 + u * 256 + threadIdx.x;
+    for (int u = 0; u < U; ++u) {
+        const int c = chunk * (256 * U) + u * 256 + threadIdx.x;
         if (c >= r.count[3]) return;
         if (SCATTER) dst[base + c * r.stride[3]] = src[(dense0 + c) % dense_ne];
         else         dst[dense0 + c] = src[base + c * r.stride[3]];
@@ -488,8 +548,9 @@ void region_typed(const void *src, void *dst, const dsc_region &r, bool scatter,
     const E *ps = (const E *) src;
     E *pd = (E *) dst;
     const long long rows = r.ne / r.count[3];
-    if (r.count[3] >= 128 && rows * ((r.count[3] + 1023) / 1024) < (1LL << 31)) {
-        const unsigned chunks = (unsigned) ((r.count[3] + 1023) / 1024);
+    constexpr int per_block = 256 * region_u<E>();
+    if (r.count[3] >= 128 && rows * ((r.count[3] + per_block - 1) / per_block) < (1LL << 31)) {
+        const unsigned chunks = (unsigned) ((r.count[3] + per_block - 1) / per_block);
         const dim3 grid((unsigned) (rows * chunks));
         if (scatter) DSC_LAUNCH((region_rows_kernel<E, true>), grid, dim3(256), 0, s, ps, pd, r, chunks, dense_ne);
         else         DSC_LAUNCH((region_rows_kernel<E, false>), grid, dim3(256), 0, s, ps, pd, r, chunks, dense_ne);

@@ -230,6 +230,22 @@ def test_binary_ops_small_operand_packed(dsc, dt):
     assert_close((odd * 3).numpy(), port.binary(a[1:], np.array([3]).astype(dt), 2))
 
 
+@pytest.mark.parametrize('dt', [np.float32, np.float64, np.complex64, np.complex128])
+def test_binary_ops_general_broadcast_packed(dsc, dt):
+    """General broadcasts whose innermost rows are whole 16-byte packs (binary_bcast_pack_kernel) and ones that are not."""
+    from oracle import port
+    rng = np.random.default_rng(24)
+    for sa, sb in (((4, 3, 8, 64), (4, 1, 8, 1)), ((3, 1, 64), (4, 1, 8, 1)), ((16, 1), (16, 72)), ((5, 1, 24), (1, 7, 24)),
+                   ((2, 3, 4, 6), (3, 1, 6)), ((4, 1, 8, 1), (4, 3, 8, 63))):
+        a, b = _rand(rng, sa, dt), _rand(rng, sb, dt)
+        for op, f in ((0, dsc.add), (1, dsc.sub), (2, dsc.mul), (3, dsc.true_div)):
+            got, want = f(dsc.from_numpy(a), dsc.from_numpy(b)).numpy(), port.binary(a, b, op)
+            if op >= 2:
+                assert_close(got, want, what=f'op {op} {sa} {sb}')
+            else:
+                assert np.array_equal(got, want), (sa, sb, op)
+
+
 def test_unary_and_cast_packed_and_tails(dsc):
     """abs / angle / conj / real / imag and casts on element counts that are and are not multiples of the pack width."""
     from oracle import port
