@@ -180,7 +180,18 @@ __global__ __launch_bounds__(256) void reduce_row_kernel(const void *x, void *ou
         const long long base = row * axis_n;
         acc_t<R, CPLX> acc = acc_init<R, CPLX, OP>();
         int last_nan = -1;
-        for (int j = threadIdx.x; j < axis_n; j += 256) {
+        int j = threadIdx.x;
+        for (; j + 3 * 256 < axis_n; j += 4 * 256) {       // four loads in flight, consumed in ascending order (max / min c32: 46-61 -> 70 %)
+            acc_t<R, CPLX> v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = load_elem<R, CPLX>(x, base + j + u * 256, j + u * 256);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (OP >= 2 && v[u].r != v[u].r) last_nan = j + u * 256;
+                else acc = combine<R, CPLX, OP>(acc, v[u]);
+            }
+        }
+        for (; j < axis_n; j += 256) {
             const acc_t<R, CPLX> v = load_elem<R, CPLX>(x, base + j, j);
             if (OP >= 2 && v.r != v.r) last_nan = j;       // j ascends: the thread's last NaN
             else acc = combine<R, CPLX, OP>(acc, v);
