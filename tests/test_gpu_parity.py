@@ -476,7 +476,8 @@ def test_transpose_every_permutation_and_aligned_slices(dsc):
     import itertools
     rng = np.random.default_rng(90)
     for dt in (np.float32, np.float64, np.complex64, np.complex128):
-        for shape in ((33, 65), (3, 37, 41), (2, 3, 35, 37), (5, 33, 4, 66)):
+        # extents that are multiples of 4: the 16-byte tile kernel (transpose_plane_vec_kernel), with partial tiles
+        for shape in ((33, 65), (3, 37, 41), (2, 3, 35, 37), (5, 33, 4, 66), (68, 132), (4, 72, 136), (2, 4, 36, 68), (8, 100)):
             x = rng.standard_normal(shape).astype(dt)
             if np.dtype(dt).kind == 'c':
                 x = (x + 1j * rng.standard_normal(shape)).astype(dt)
