@@ -197,6 +197,11 @@ __device__ __forceinline__ void buf_store(cpx<float> a, __amdgpu_buffer_rsrc_t r
 template<int POL = kCached>
 __device__ __forceinline__ void buf_store(cpx<double> a, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, d2{a.x, a.y}), r, voff, soff, POL);
+    // The data registers of a 128-bit store must not be rewritten by the very next VALU instruction: on gfx950, with f64 data at
+    // two waves per SIMD, the last quad of a 16-lane row now and then stores the NEXT value (hipcc pads this hazard only for a
+    // literal soffset; found by tools/stress_fused.py, again by tests/test_gpu_headline.py::test_every_element_of_the_f64_paths
+    // when the 2048-point f64 configuration changed its schedule).  Two wait states after every such store cost nothing.
+    asm volatile("s_nop 1");
 }
 
 }  // namespace
