@@ -46,8 +46,14 @@ template<typename R, int B, bool TWO> struct mid_cfg {
     // Three-pass lines of 2048 points (B = 2): the last exchange keeps its 2-value rows UNPADDED and reads a row as one 8- /
     // 16-byte access (conflict free, like the stride-1 writes) — the padded pitch 3 cost 50 % more LDS and left two 256-thread
     // groups (two waves per SIMD) on a CU in f32; unpadded, two 512-thread groups fit (four per SIMD): irfft N = 4096 64.6 ->
-    // 71 %, fft 68 -> 73 %, fused filter 31 -> 38.6 %.  (B = 4 measured too: 1 % slower, stays padded.)
+    // 71 %, fft 68 -> 73 %, fused filter 31 -> 38.6 %.  (f32 B = 4 measured too: 1 % slower, stays padded.)  f64 B = 4 (4096-point
+    // lines, one 128-thread group per line): 4-value rows unpadded, read as two 16-byte accesses (2-way conflicts) — three groups
+    // per CU instead of two: rfft N = 8192 62.5 -> 69.3 %, irfft 60 -> 71.2 %, fft c64 71 -> 78.7 %.
+#ifdef DSC_MID_NO_F64_B4
     static constexpr bool PACKED = !TWO && B == 2;
+#else
+    static constexpr bool PACKED = !TWO && (B == 2 || (DP && B == 4));
+#endif
 #endif
     static constexpr int NT = DP ? (TWO ? (B >= 32 ? 128 : 256) : (B >= 8 ? 512 : 128))
                                  : (TWO ? 256 : B >= 32 ? 1024 : (B >= 8 || (PACKED && !DP)) ? 512 : 256);
