@@ -55,7 +55,15 @@ template<typename R, int B, bool TWO> struct mid_cfg {
     static constexpr bool PACKED = !TWO && (B == 2 || (DP && B == 4));
 #endif
 #endif
-    static constexpr int NT = DP ? (TWO ? (B >= 32 ? 128 : 256) : (B >= 8 ? 512 : 128))
+#ifdef DSC_MID_NO_HALF_TABLE
+    static constexpr bool HALF = false;
+#else
+    // f64 lines of 8192 points (B = 8): two lines per 512-thread group filled the whole LDS (144 KiB plane + 16 KiB table), i.e. ONE
+    // group per CU with nothing to overlap its load / compute / store phases with.  One line per 256-thread group and HALF the
+    // W_1024 table (W^(m + 512) = -W^m) is exactly 80 KiB: two independent groups per CU.
+    static constexpr bool HALF = DP && !TWO && B == 8;
+#endif
+    static constexpr int NT = DP ? (TWO ? (B >= 32 ? 128 : 256) : HALF ? 256 : (B >= 8 ? 512 : 128))
                                  : (TWO ? 256 : B >= 32 ? 1024 : (B >= 8 || (PACKED && !DP)) ? 512 : 256);
     static constexpr int G = NT / T;                 // lines per workgroup
     static constexpr int WAVES_PER_EU = DP ? 2 : (TWO ? 2 : (B >= 8 || PACKED) ? 4 : 2);   // f32: <= 128 VGPRs where two 512-thread groups share a CU
@@ -69,12 +77,23 @@ template<typename R, int B, bool TWO> struct mid_cfg {
     static constexpr int PLANE_X1 = TWO ? 0 : G * T * 33, PLANE_ST = G * (32 * T + 1);
     static constexpr int PLANE = ((PLANE_MIN > PLANE_X1 ? (PLANE_MIN > PLANE_ST ? PLANE_MIN : PLANE_ST) : (PLANE_X1 > PLANE_ST ? PLANE_X1 : PLANE_ST)) + 3) & ~3;
     static constexpr int CPT = 32 / B;               // columns per thread in the last pass
-    static constexpr int TABLE = TWO ? L : 1024;     // LDS twiddle table: W_L^m (two-pass) or W_1024^m
+    static constexpr int TABLE = TWO ? L : HALF ? 512 : 1024;     // LDS twiddle table: W_L^m (two-pass) or W_1024^m (HALF: m < 512)
     static constexpr int TABLE_STRIDE = TWO ? 1 : B;
 };
 
 template<typename R, int B, bool TWO>
 constexpr size_t mid_lds_bytes() { return ((size_t) mid_cfg<R, B, TWO>::PLANE + 2 * mid_cfg<R, B, TWO>::TABLE) * sizeof(R); }
+
+// W_1024^m from the LDS table; HALF: the table holds m < 512 and W^(m + 512) = -W^m
+template<typename R, bool HALF>
+__device__ __forceinline__ cpx<R> table_entry(const cpx<R> *wtab, int m) {
+    if constexpr (HALF) {
+        const cpx<R> w = wtab[m & 511];
+        return (m & 512) ? cpx<R>{-w.x, -w.y} : w;
+    } else {
+        return wtab[m];
+    }
+}
 
 // The transform proper, shared by fft_mid_kernel and fft_mid_filter_kernel.  In: v[j1] = z[T j1 + t] of line g (natural
 // register order).  Out: v[i B + p] = bin k = (t + T i) + COLS brev(p) ("column layout").  Ends with an LDS barrier, i.e.
@@ -92,7 +111,7 @@ __device__ __forceinline__ void mid_passes(cpx<R> (&v)[32], R *plane, const cpx<
         dft_n<R, INV, 32>(v);
 #pragma unroll
         for (int k1 = 1; k1 < 32; ++k1) {
-            const C w = wtab[hi * k1];
+            const C w = table_entry<R, cfg::HALF>(wtab, hi * k1);
             v[brev(k1, 5)] = INV ? cmulc(v[brev(k1, 5)], w) : cmul(v[brev(k1, 5)], w);
         }
         // ---- exchange 1: (j2, j3)[k1] -> thread B k1 + j3, [j2]
@@ -127,7 +146,7 @@ __device__ __forceinline__ void mid_passes(cpx<R> (&v)[32], R *plane, const cpx<
             u[0] = INV ? cmulc(u[0], tw2_base) : cmul(u[0], tw2_base);
 #pragma unroll
             for (int k2 = 1; k2 < 32; ++k2) {
-                const C w = cmul(tw2_base, wtab[(32 / B) * lo * k2]);
+                const C w = cmul(tw2_base, table_entry<R, cfg::HALF>(wtab, (32 / B) * lo * k2));
                 u[brev(k2, 5)] = INV ? cmulc(u[brev(k2, 5)], w) : cmul(u[brev(k2, 5)], w);
             }
         } else {
