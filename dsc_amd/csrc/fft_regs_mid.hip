@@ -32,6 +32,15 @@ namespace {
 
 // TWO = false: L = 1024 B, three passes (32 x 32 x B), T = 32 B threads per line.
 // TWO = true:  L = 32 B,   two passes  (32 x B),       T = B threads per line (a wave holds 64 / B lines).
+constexpr int two_pass_stride(int B) {
+    const int base = 32 * (B + 1);
+    for (int p = 0; p < 64; ++p) {
+        const int r = (base + p) % 64;
+        if (B >= 64 || (r % B == 0 && ((r / B) & 1))) return base + p;
+    }
+    return base;
+}
+
 template<typename R, int B, bool TWO> struct mid_cfg {
     static constexpr bool DP = sizeof(R) == 8;
     static constexpr int T = TWO ? B : 32 * B;       // threads per line
@@ -55,7 +64,7 @@ template<typename R, int B, bool TWO> struct mid_cfg {
     static constexpr bool PACKED = !TWO && (B == 2 || (DP && B == 4));
 #endif
 #endif
-#ifdef DSC_MID_NO_HALF_TABLE
+#ifdef DSC_MID_NO_HALF_TABLE   // (A/B switch)
     static constexpr bool HALF = false;
 #else
     // f64 lines of 8192 points (B = 8): two lines per 512-thread group filled the whole LDS (144 KiB plane + 16 KiB table), i.e. ONE
@@ -70,9 +79,12 @@ template<typename R, int B, bool TWO> struct mid_cfg {
     static constexpr int P1 = 33;                    // exchange-1 row pitch (values): odd
     static constexpr int P2 = PACKED ? B : B + 1;    // last-exchange row pitch
     static constexpr int SP = L + 1;                 // staging pitch per line (bins 0 .. L)
-    // values per line in the last exchange.  Two-pass: padded so that the stride is = B mod 64 — the lanes of a wave are
-    // (line, j3) pairs and then hit 64 different banks (an unpadded 32 (B + 1) is = 32 mod 64: up to 16-way conflicts)
-    static constexpr int LSTRIDE = TWO ? 32 * (B + 1) + (((B - 32 - 32 * B) % 64) + 64) % 64 : 1024 * P2;
+    // values per line in the last exchange.  Two-pass: padded so that the stride is an ODD multiple of B mod 64 — the lanes of a
+    // wave are (line, j3) pairs and then hit 64 different banks (an unpadded 32 (B + 1) is = 32 mod 64: up to 16-way conflicts).
+    // f64 takes the SMALLEST such pad: with stride = B mod 64 the 512-point lines (B = 16) carry 48 spare values each, which cost
+    // the second workgroup per CU (83.8 -> 79.7 KiB: rfft f64 N = 1024 63.7 -> 67.9 %, irfft 64.3 -> 69.2 %).  In f32 the same
+    // change buys a fourth workgroup (41.9 -> 39.9 KiB) and measured 1-2 % SLOWER: f32 keeps stride = B mod 64.
+    static constexpr int LSTRIDE = TWO ? (DP ? two_pass_stride(B) : 32 * (B + 1) + (((B - 32 - 32 * B) % 64) + 64) % 64) : 1024 * P2;
     static constexpr int PLANE_MIN = G * LSTRIDE;    // padded: >= G*T*P1 (three-pass) and >= G*SP; unpadded rows: take the largest
     static constexpr int PLANE_X1 = TWO ? 0 : G * T * 33, PLANE_ST = G * (32 * T + 1);
     static constexpr int PLANE = ((PLANE_MIN > PLANE_X1 ? (PLANE_MIN > PLANE_ST ? PLANE_MIN : PLANE_ST) : (PLANE_X1 > PLANE_ST ? PLANE_X1 : PLANE_ST)) + 3) & ~3;
