@@ -196,12 +196,16 @@ __device__ __forceinline__ void buf_store(cpx<float> a, __amdgpu_buffer_rsrc_t r
 }
 template<int POL = kCached>
 __device__ __forceinline__ void buf_store(cpx<double> a, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, d2{a.x, a.y}), r, voff, soff, POL);
-    // The data registers of a 128-bit store must not be rewritten by the very next VALU instruction: on gfx950, with f64 data at
-    // two waves per SIMD, the last quad of a 16-lane row now and then stores the NEXT value (hipcc pads this hazard only for a
-    // literal soffset; found by tools/stress_fused.py, again by tests/test_gpu_headline.py::test_every_element_of_the_f64_paths
-    // when the 2048-point f64 configuration changed its schedule).  Two wait states after every such store cost nothing.
-    asm volatile("s_nop 1");
+    const u4 data = __builtin_bit_cast(u4, d2{a.x, a.y});
+    __builtin_amdgcn_raw_buffer_store_b128(data, r, voff, soff, POL);
+    // The data registers of a 128-bit buffer store must not be rewritten by a VALU instruction in the next two issue slots: on
+    // gfx950, with f64 data at two or more waves per SIMD, the last quad of every 16-lane row now and then stores the NEXT value
+    // (hipcc pads this hazard only for a literal soffset).  Found by tools/stress_fused.py, and again — one row in a few thousand,
+    // bins 396-399, 412-415, 428-431, 444-447: lanes 12-15 of each row of one store instruction — by
+    // tests/test_gpu_headline.py::test_every_element_of_the_f64_paths when the 2048-point f64 configuration changed its schedule.
+    // A bare s_nop after the store is not enough: the scheduler may move the overwriting instruction in front of it.  The wait
+    // states therefore READ the data registers, so that nothing can overwrite them before the nop has issued.
+    asm volatile("s_nop 1" : : "v"(data));
 }
 
 }  // namespace

@@ -90,8 +90,7 @@ __device__ __forceinline__ void l2_store(unsigned *p, unsigned v) {
 // literal soffset; two wait states after every such store cost nothing here.
 template<int POL, typename R>
 __device__ __forceinline__ void st(cpx<R> a, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    buf_store<POL>(a, r, voff, soff);
-    if constexpr (sizeof(R) == 8) asm volatile("s_nop 1");
+    buf_store<POL>(a, r, voff, soff);                       // the c64 form carries the two wait states, tied to its data registers
 }
 
 template<typename R, bool INV, int M, int G, int... K>

@@ -505,7 +505,13 @@ def test_every_element_of_the_f64_paths_with_128_bit_stores(dsc):
     rng = np.random.default_rng(64)
 
     def worst(got, want):
-        return float(np.max(np.abs(got - want) / np.max(np.abs(want), axis=1, keepdims=True)))
+        err = np.abs(got - want) / np.max(np.abs(want), axis=1, keepdims=True)
+        w = float(np.max(err))
+        if not w <= 1e-12:                                   # say WHERE: a race or a hazard shows in the pattern
+            bad = np.argwhere(~(err <= 1e-12))
+            print(f'{len(bad)} wrong elements; rows {sorted(set(bad[:, 0].tolist()))[:16]}; columns {sorted(set(bad[:, 1].tolist()))[:48]}; '
+                  f'first got {got[tuple(bad[0])]} want {want[tuple(bad[0])]}')
+        return w
 
     for n, rows in ((4096, 2048), (524288, 12)):
         xd = rng.standard_normal((rows, n))
@@ -513,7 +519,7 @@ def test_every_element_of_the_f64_paths_with_128_bit_stores(dsc):
         zd = rng.standard_normal((rows, n // 2)) + 1j * rng.standard_normal((rows, n // 2))
         wz = np.fft.fft(zd, axis=-1)
         td, tD, tz = dsc.from_numpy(xd), dsc.from_numpy(wd), dsc.from_numpy(zd)
-        for rep in range(3):
+        for rep in range(12 if n == 4096 else 3):            # the store-data hazard showed in one row of a few thousand
             assert worst(dsc.rfft(td).numpy(), wd) <= 1e-12, (n, rep, 'rfft', dsc.last_fft_path())
             assert worst(dsc.irfft(tD).numpy(), xd) <= 1e-12, (n, rep, 'irfft', dsc.last_fft_path())
             assert worst(dsc.fft(tz).numpy(), wz) <= 1e-12, (n, rep, 'fft', dsc.last_fft_path())
