@@ -513,7 +513,7 @@ def test_every_element_of_the_f64_paths_with_128_bit_stores(dsc):
                   f'first got {got[tuple(bad[0])]} want {want[tuple(bad[0])]}')
         return w
 
-    for n, rows in ((4096, 2048), (524288, 12)):
+    for n, rows in ((4096, 2048), (1024, 4096), (8192, 1024), (16384, 512), (524288, 12)):      # every f64 configuration of fft_mid_kernel that stores 128 bits
         xd = rng.standard_normal((rows, n))
         wd = np.fft.rfft(xd, axis=-1)
         zd = rng.standard_normal((rows, n // 2)) + 1j * rng.standard_normal((rows, n // 2))

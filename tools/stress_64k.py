@@ -34,7 +34,7 @@ for rep in range(8):
     check('c2c32k', dsc.fft(tz).numpy(), wz, 2e-5)
 del tx, tX, tz
 # f64: mid-size register kernel (2 waves per SIMD, 128-bit stores) and the two-pass kernels
-for n, rows in ((4096, 4096), (32768, 512), (65536, 256), (524288, 24)):
+for n, rows in ((4096, 4096), (1024, 8192), (8192, 2048), (16384, 1024), (32768, 512), (65536, 256), (524288, 24)):
     xd = rng.standard_normal((rows, n))
     wd = np.fft.rfft(xd, axis=-1)
     td, tD = dsc.from_numpy(xd), dsc.from_numpy(wd)
