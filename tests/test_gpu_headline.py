@@ -847,6 +847,24 @@ def test_generic_four_step_beyond_the_two_pass_lengths(dsc):
 
 
 @pytest.mark.parametrize('dt', [np.float32, np.float64])
+def test_fft_of_real_tensors_beyond_262144_points_widen_then_two_pass(dsc, dt):
+    """dsc_fft / dsc_ifft of REAL rows of 524288 and 1048576 points: widened into a complex temporary, then the complex two-pass
+    route (the generic four-step path ran at 6 % of the roofline); full, zero-padded and cropped rows."""
+    rng = np.random.default_rng(77)
+    tol = 2e-6 if dt == np.float32 else 1e-12
+    for L in (524288, 1048576):
+        x = rng.standard_normal((3, L)).astype(dt)
+        t = dsc.from_numpy(x)
+        assert rel_l2(dsc.fft(t).numpy(), np.fft.fft(x.astype(np.float64), axis=-1)) <= tol and dsc.last_fft_path() == 'c2c_2pass_regs'
+        assert rel_l2(dsc.ifft(t).numpy(), np.fft.ifft(x.astype(np.float64), axis=-1)) <= tol and dsc.last_fft_path() == 'c2c_2pass_regs'
+    short = rng.standard_normal((2, 400000)).astype(dt)                     # n= pads to 524288
+    assert rel_l2(dsc.fft(dsc.from_numpy(short), n=524288).numpy(), np.fft.fft(short.astype(np.float64), n=524288, axis=-1)) <= tol
+    assert dsc.last_fft_path() == 'c2c_2pass_regs'
+    long_ = rng.standard_normal((2, 600000)).astype(dt)                     # n= crops to 524288
+    assert rel_l2(dsc.fft(dsc.from_numpy(long_), n=524288).numpy(), np.fft.fft(long_.astype(np.float64), n=524288, axis=-1)) <= tol
+
+
+@pytest.mark.parametrize('dt', [np.float32, np.float64])
 def test_every_power_of_two_length(dsc, dt):
     """One sweep over every transform length 2 .. 2^20, all four transforms, full and zero-padded rows,
     against float64 numpy: whatever kernel path a length takes, the result must be within the precision's tolerance."""
