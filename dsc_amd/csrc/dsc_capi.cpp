@@ -358,11 +358,27 @@ static dsc_tensor *binary_entry(dsc_ctx *ctx, dsc_tensor *xa, dsc_tensor *xb, ds
         }
         return true;
     };
+    // ... or exactly the LEADING dims (a [B, K] tensor scaled by a [B, 1] column): index = i / (elements per small element)
+    auto leading = [&](const dsc_tensor *small, long long *per) {
+        bool ones = false;
+        long long inner = 1;
+        for (int i = 0; i < DSC_MAX_DIMS; ++i) {
+            if (!ones && small->shape[i] == shape[i]) continue;
+            if (small->shape[i] != 1) return false;
+            ones = true;
+            inner *= shape[i];
+        }
+        *per = inner;
+        return ones && inner > 1 && inner < (1LL << 31);
+    };
     g.fast = 0;
     g.small_ne = 1;
+    long long per = 0;
     if (xa->ne == out->ne && xb->ne == out->ne) g.fast = 1;
     else if (xa->ne == out->ne && trailing(xb)) { g.fast = 2; g.small_ne = xb->ne; }
     else if (xb->ne == out->ne && trailing(xa)) { g.fast = 3; g.small_ne = xa->ne; }
+    else if (xa->ne == out->ne && leading(xb, &per)) { g.fast = 4; g.small_ne = (int) per; }
+    else if (xb->ne == out->ne && leading(xa, &per)) { g.fast = 5; g.small_ne = (int) per; }
     dsc_launch_binary(ca->data, cb->data, out->data, out_dtype, op, g, ctx->stream);
 
     if (ca != xa) drop_scratch_tensor(ctx, ca);

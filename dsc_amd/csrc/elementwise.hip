@@ -214,10 +214,41 @@ __global__ void binary_small_pack_kernel(const T *big, const T *small, T *out, u
     }
 }
 
+// The small operand spans the LEADING dims (a [B, K] tensor against a [B, 1] column): element e of the result takes small[e / per];
+// one division per thread, then the index steps when a pack crosses a row end.
+template<typename T, int OP, bool BIG_IS_A>
+__global__ void binary_column_pack_kernel(const T *big, const T *small, T *out, unsigned npack, unsigned per) {
+    constexpr int V = 16 / sizeof(T);
+    const packed<T, V> *pbig = (const packed<T, V> *) big;
+    packed<T, V> *po = (packed<T, V> *) out;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < npack; i += gridDim.x * blockDim.x) {
+        const packed<T, V> x = pbig[i];
+        const unsigned long long e0 = (unsigned long long) i * V;
+        unsigned q = (unsigned) (e0 / per), m = (unsigned) (e0 - (unsigned long long) q * per);
+        packed<T, V> r;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const T sv = small[q];
+            r.e[j] = BIG_IS_A ? apply<T, OP>(x.e[j], sv) : apply<T, OP>(sv, x.e[j]);
+            if (++m >= per) { m = 0; ++q; }
+        }
+        po[i] = r;
+    }
+}
+
 template<typename T, int OP>
 bool binary_fast(const T *pa, const T *pb, T *po, const dsc_bcast_args &g, dim3 grid, hipStream_t s) {
     constexpr unsigned V = 16 / sizeof(T);
-    if ((g.a_scalar || g.b_scalar || g.fast >= 2) && g.ne % V == 0) {
+    if (g.fast >= 4 && !g.a_scalar && !g.b_scalar) {
+        const bool big_is_a = g.fast == 4;
+        const T *big = big_is_a ? pa : pb, *small = big_is_a ? pb : pa;
+        if (g.ne % V != 0 || !aligned_to(big, 16) || !aligned_to(po, 16) || g.small_ne < (int) V) return false;
+        const unsigned npack = (unsigned) (g.ne / V);
+        if (big_is_a) DSC_LAUNCH((binary_column_pack_kernel<T, OP, true>), pack_grid(npack), dim3(256), 0, s, big, small, po, npack, (unsigned) g.small_ne);
+        else          DSC_LAUNCH((binary_column_pack_kernel<T, OP, false>), pack_grid(npack), dim3(256), 0, s, big, small, po, npack, (unsigned) g.small_ne);
+        return true;
+    }
+    if ((g.a_scalar || g.b_scalar || g.fast == 2 || g.fast == 3) && g.ne % V == 0) {
         const bool big_is_a = g.b_scalar || (!g.a_scalar && g.fast == 2);
         const T *big = big_is_a ? pa : pb, *small = big_is_a ? pb : pa;
         const unsigned sm = (g.a_scalar || g.b_scalar) ? 1u : (unsigned) g.small_ne;
@@ -228,7 +259,7 @@ bool binary_fast(const T *pa, const T *pb, T *po, const dsc_bcast_args &g, dim3 
             return true;
         }
     }
-    if (g.a_scalar || g.b_scalar || g.fast == 0) return false;
+    if (g.a_scalar || g.b_scalar || g.fast == 0 || g.fast >= 4) return false;
     const unsigned ne = (unsigned) g.ne, sm = (unsigned) g.small_ne;
     if (g.fast == 1 && V > 1 && ne % V == 0 && (((size_t) pa | (size_t) pb | (size_t) po) & 15) == 0) {
         DSC_LAUNCH((binary_same_vec_kernel<T, OP>), pack_grid(ne / V), dim3(256), 0, s, pa, pb, po, ne / V);

@@ -172,9 +172,10 @@ struct dsc_bcast_args {
     long long ne;
     int a_scalar, b_scalar;   // reference's scalar fast paths (dsc.cpp:1194-1212)
     // index fast paths (no per-element divisions): 0 general, 1 both operands have the output's shape,
-    // 2 a full / b = the trailing dims of the output (row broadcast: ib = i % b_ne), 3 the converse
+    // 2 a full / b = the trailing dims of the output (row broadcast: ib = i % b_ne), 3 the converse,
+    // 4 a full / b = the leading dims of the output, ones behind (column broadcast: ib = i / small_ne), 5 the converse
     int fast;
-    int small_ne;             // element count of the broadcast operand for fast = 2, 3
+    int small_ne;             // fast = 2, 3: element count of the broadcast operand; fast = 4, 5: output elements per element of it
 };
 // op: 0 add, 1 sub, 2 mul, 3 div   (only mul is exported through the C ABI this round)
 void dsc_launch_binary(const void *a, const void *b, void *out, int dtype, int op, const dsc_bcast_args &g, hipStream_t stream);

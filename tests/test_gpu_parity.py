@@ -236,6 +236,8 @@ def test_binary_ops_general_broadcast_packed(dsc, dt):
     from oracle import port
     rng = np.random.default_rng(24)
     for sa, sb in (((4, 3, 8, 64), (4, 1, 8, 1)), ((3, 1, 64), (4, 1, 8, 1)), ((16, 1), (16, 72)), ((5, 1, 24), (1, 7, 24)),
+                   ((12, 513), (12, 1)), ((6, 1, 1), (6, 5, 22)), ((2, 3, 1, 1), (2, 3, 7, 10)), ((9, 2), (9, 1)),      # column broadcasts
+
                    ((2, 3, 4, 6), (3, 1, 6)), ((4, 1, 8, 1), (4, 3, 8, 63))):
         a, b = _rand(rng, sa, dt), _rand(rng, sb, dt)
         for op, f in ((0, dsc.add), (1, dsc.sub), (2, dsc.mul), (3, dsc.true_div)):
