@@ -109,6 +109,21 @@ def _filter_mid(dsc, B, ctx, np):
     return (lambda: B.dsc_filter_fft(ctx, s._c_ptr, H._c_ptr, y._c_ptr)), batch * n * 8, (s, y, H)
 
 
+def _filter_mid_case(n, batch):
+    def make(dsc, B, ctx, np):
+        rng = np.random.default_rng(5)
+        blk = rng.standard_normal((64, n)).astype(np.float32)
+        s = dsc.from_numpy(np.tile(blk, (batch // 64, 1)))
+        y = dsc.empty((batch, n), dsc.Dtype.F32)
+        H = dsc.from_numpy((rng.standard_normal(n // 2 + 1) + 1j * rng.standard_normal(n // 2 + 1)).astype(np.complex64))
+        return (lambda: B.dsc_filter_fft(ctx, s._c_ptr, H._c_ptr, y._c_ptr)), batch * n * 8, (s, y, H)
+    return make
+
+
+CASES['filter_f32_32768'] = _filter_mid_case(32768, 8192)
+CASES['filter_f32_16384'] = _filter_mid_case(16384, 16384)
+
+
 @case('rfft_axis0_4096x8192')
 def _axis0(dsc, B, ctx, np):
     rng = np.random.default_rng(6)
