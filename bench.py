@@ -340,7 +340,14 @@ def main():
     # configs[4] rfft f64 N=262144): each a full roofline object, reported next to the metric, never part of `value`
     if not args.dry_run and not args.no_other_kernels:
         try:
-            def timed(f, n=args.steps):
+            def timed(f, n=max(args.steps, 50)):
+                # the host-side setup before each of these kernels (uploads of a GiB) leaves the GPU idle and its clocks low: the
+                # same untimed ramp as the metric's loop, then max(W, 10) warm-up launches
+                t_end = time.perf_counter() + args.ramp_ms / 1e3
+                while time.perf_counter() < t_end:
+                    for _ in range(10):
+                        f()
+                    dsc.synchronize()
                 for _ in range(max(10, args.warmup)):
                     f()
                 dsc.synchronize()
