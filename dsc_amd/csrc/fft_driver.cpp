@@ -357,13 +357,13 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
         const long long x_n = j.x->shape[j.slot];
         const size_t tmp_bytes = (size_t) n_lines * (size_t) x_n * (sp ? 8 : 16);
         if (n_lines * x_n < (1LL << 31) && n_lines < (1LL << 31) && ctx->main.fits(tmp_bytes)) {
-            const int shp[2] = {(int) n_lines, (int) x_n};
-            dsc_tensor *wide = dsc_new_tensor(ctx, 2, shp, sp ? DSC_C32 : DSC_C64, nullptr);
+            // x's own shape in the complex dtype: the axis slot stays where it is, so that the recursive call counts the lines of
+            // `wide` and of `out` the same way also when trailing unit dimensions follow the axis ([B, N, 1], axis 1)
+            dsc_tensor *wide = dsc_new_tensor(ctx, j.x->n_dim, &j.x->shape[DSC_MAX_DIMS - j.x->n_dim], sp ? DSC_C32 : DSC_C64, nullptr);
             dsc_launch_cast(j.x->data, j.x->dtype, wide->data, wide->dtype, n_lines * x_n, ctx->stream);
             fft_job j2 = j;
             j2.x = wide;
             j2.mode = DSC_MODE_C2C;
-            j2.slot = DSC_MAX_DIMS - 1;
             run_job(ctx, j2);
             dsc_tensor_free(ctx, wide);                  // stream ordered
             return;

@@ -865,6 +865,31 @@ def test_fft_of_real_tensors_beyond_262144_points_widen_then_two_pass(dsc, dt):
 
 
 @pytest.mark.parametrize('dt', [np.float32, np.float64])
+def test_trailing_unit_dimensions_after_the_axis(dsc, dt):
+    """x of shape [B, N, 1] (or [B, N, 1, 1]) transformed along axis 1: the lines are contiguous (inner == 1) although the axis is
+    not the last slot.  Every contiguous-row route must count the lines of x and of out the same way — the route that widens
+    real rows of 524288 points into a complex temporary once rewrote the slot of x only and wrote past the end of `out`."""
+    rng = np.random.default_rng(5)
+    cdt = np.complex64 if dt == np.float32 else np.complex128
+    tol = 2e-6 if dt == np.float32 else 1e-12
+    for n, want_path in ((64, None), (1024, None), (8192, None), (65536, None), (131072, None), (524288, 'c2c_2pass_regs')):
+        for tail in ((1,), (1, 1)):
+            x = rng.standard_normal((3, n) + tail).astype(dt)
+            ref = np.fft.fft(x.astype(np.float64), axis=1)
+            guard = dsc.from_numpy(np.full((3, n) + tail, 7 + 7j, cdt))     # allocated right behind `out` by the best-fit arena
+            got = dsc.fft(dsc.from_numpy(x), axis=1)
+            assert got.shape == x.shape and rel_l2(got.numpy(), ref) <= tol, (n, tail, dsc.last_fft_path())
+            if want_path:
+                assert dsc.last_fft_path() == want_path
+            assert rel_l2(dsc.ifft(dsc.from_numpy(x), axis=1).numpy(), np.fft.ifft(x.astype(np.float64), axis=1)) <= tol
+            assert rel_l2(dsc.rfft(dsc.from_numpy(x), axis=1).numpy(), np.fft.rfft(x.astype(np.float64), axis=1)) <= tol, (n, tail)
+            X = np.fft.rfft(x.astype(np.float64), axis=1).astype(cdt)
+            assert rel_l2(dsc.irfft(dsc.from_numpy(X), axis=1).numpy(), x) <= 2 * tol, (n, tail)
+            assert np.all(guard.numpy() == 7 + 7j), (n, tail)
+            del guard, got
+
+
+@pytest.mark.parametrize('dt', [np.float32, np.float64])
 def test_every_power_of_two_length(dsc, dt):
     """One sweep over every transform length 2 .. 2^20, all four transforms, full and zero-padded rows,
     against float64 numpy: whatever kernel path a length takes, the result must be within the precision's tolerance."""
