@@ -19,7 +19,11 @@ Prints ONE JSON line on rank 0.  Extra keys beyond the driver's contract:
   allgather     the shard-reassembly phase (dsc_amd/shard.py): every method timed and verified (N > 1 only)
   cpu_baseline  the reference's own CPU code (oracle/_ref, kind "reference") or our C
                 restatement (kind "port") timed on this host, rank 0, N == 1 only
-  parity        rel-L2 of a few GPU rows against the CPU oracle (checker, not timed)
+  parity        SURVEY 8d's on-device check (untimed): first / last 4 rows + 64 seeded random rows against the CPU oracle, and
+                Parseval's identity on ALL rows, evaluated on the device with the product's own dsc_mul / dsc_conj / dsc_sum
+  min_ms, median_ms   per-step HIP-event times of the K timed steps (the reference reports the minimum, utils.py:11-12)
+  config4_on_one_gpu  N == 1 only: the 65536 rows of BASELINE configs[3] as 8 sequential 8192-row launches on this GPU — the
+                like-for-like denominator of the 8-GPU line
 """
 import argparse
 import contextlib
@@ -96,6 +100,65 @@ def cpu_baseline(rows=1024, reps=5, warm=2):
     }
 
 
+def device_parity(dsc, B, ctx, x, out, x_host, rows, rank):
+    """SURVEY 8d, untimed.  (1) first / last 4 rows + 64 seeded random rows of the spectrum on the device against the CPU oracle
+    (rel-L2 per row, tolerance 1e-5).  (2) Parseval on EVERY row with the product's own operators:
+    sum_n x[n]^2 == (2 sum_k |X[k]|^2 - |X[0]|^2 - |X[N/2]|^2) / N, left side dsc_sum(dsc_mul(x, x)), right side
+    dsc_sum(dsc_mul(X, dsc_conj(X))) — 1024 rows at a time through views, so that the temporaries stay under 1 GiB."""
+    import ctypes
+    import numpy as np
+    from oracle import port                                   # checker only
+    bins = N_FFT // 2 + 1
+    rng = np.random.default_rng(4321 + rank)
+    pick = sorted(set(list(range(min(4, rows))) + list(range(max(0, rows - 4), rows)) + [int(r) for r in rng.integers(0, rows, size=min(64, rows))]))
+    x_ptr, o_ptr = x._c_ptr.contents.data, out._c_ptr.contents.data
+    got = np.empty((len(pick), bins), np.complex64)
+    shp1 = (ctypes.c_int * 2)(1, bins)
+    for i, r in enumerate(pick):
+        v = B.dsc_tensor_from_device_ptr(ctx, o_ptr + r * bins * 8, bins * 8, 2, shp1, int(dsc.Dtype.C32))
+        B.dsc_copy_to_host(ctx, v, got[i].ctypes.data, bins * 8)
+        B.dsc_tensor_free(ctx, v)
+    want = port.rfft(x_host[pick])
+    per_row = np.linalg.norm(got - want, axis=1) / np.linalg.norm(want, axis=1)
+    # Parseval, all rows, on the device
+    worst = 0.0
+    step = min(1024, rows)
+    for r0 in range(0, rows, step):
+        n = min(step, rows - r0)
+        sx = (ctypes.c_int * 2)(n, N_FFT)
+        so = (ctypes.c_int * 2)(n, bins)
+        xv = B.dsc_tensor_from_device_ptr(ctx, x_ptr + r0 * N_FFT * 4, n * N_FFT * 4, 2, sx, int(dsc.Dtype.F32))
+        ov = B.dsc_tensor_from_device_ptr(ctx, o_ptr + r0 * bins * 8, n * bins * 8, 2, so, int(dsc.Dtype.C32))
+        xx = B.dsc_mul(ctx, xv, xv, None)
+        e_t = B.dsc_sum(ctx, xx, None, -1, True)
+        B.dsc_tensor_free(ctx, xx)
+        oc = B.dsc_conj(ctx, ov)
+        pp = B.dsc_mul(ctx, ov, oc, None)
+        B.dsc_tensor_free(ctx, oc)
+        e_f = B.dsc_sum(ctx, pp, None, -1, True)
+        B.dsc_tensor_free(ctx, pp)
+        h_t = np.empty((n, 1), np.float32)
+        h_f = np.empty((n, 1), np.complex64)
+        B.dsc_copy_to_host(ctx, e_t, h_t.ctypes.data, h_t.nbytes)
+        B.dsc_copy_to_host(ctx, e_f, h_f.ctypes.data, h_f.nbytes)
+        edge = np.empty((n, 2), np.complex64)                 # X[:, 0] and X[:, N/2]
+        for j, col in enumerate((0, bins - 1)):
+            c = B.dsc_tensor_get_slice(ctx, ov, B._DscSlice(0, n, 1), B._DscSlice(col, col + 1, 1))
+            tmp = np.empty((n, 1), np.complex64)
+            B.dsc_copy_to_host(ctx, c, tmp.ctypes.data, tmp.nbytes)
+            edge[:, j] = tmp[:, 0]
+            B.dsc_tensor_free(ctx, c)
+        for t in (e_t, e_f, xv, ov):
+            B.dsc_tensor_free(ctx, t)
+        lhs = h_t[:, 0].astype(np.float64)
+        rhs = (2.0 * h_f[:, 0].real.astype(np.float64) - np.abs(edge[:, 0].astype(np.complex128)) ** 2 - np.abs(edge[:, 1].astype(np.complex128)) ** 2) / N_FFT
+        worst = max(worst, float(np.max(np.abs(lhs - rhs) / lhs)))
+    return {'rel_l2_vs_cpu_oracle': float(per_row.max()), 'rows_checked': len(pick), 'rows': 'first 4 + last 4 + 64 seeded random (4321 + rank)',
+            'tolerance': 1e-5, 'parseval_max_rel': worst, 'parseval_rows': rows, 'parseval_tolerance': 1e-4,
+            'parseval_how': 'on the device: dsc_sum(dsc_mul(x, x)) against dsc_sum(dsc_mul(X, dsc_conj(X))), f32 accumulation',
+            'ok': bool(per_row.max() <= 1e-5 and worst <= 1e-4)}
+
+
 def recorded_traffic(kernel, nbytes):
     """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE + WRITE_SIZE, corrected as
     the guide prescribes) — NOT measured in this run: counters need their own profiled passes.  Returned only for the same
@@ -141,11 +204,13 @@ def gather_phase(args, dist, world, rank, rows, barrier_sync, gpu):
         g_rows, row_elems, chunk_rows = 96, 130, 40
         own = torch.from_numpy((1000.0 * (rank + 1) + np.arange(g_rows, dtype=np.float32)[:, None]
                                 + np.arange(row_elems, dtype=np.float32)[None, :] / 1024.0).astype(np.float32))
-        methods = [m for m in methods if m != 'ipc']
+        methods = [m for m in methods if m not in ('ipc', 'allgather_c', 'p2p_c')]
         ctx = None
     else:
         dsc, B, ctx, x = gpu
         g_rows, row_elems, chunk_rows = rows, 2 * bins, min(args.gather_chunk_rows, rows)
+        if not on_device:                                 # the library's own RCCL communicator needs one GPU per rank
+            methods = [m for m in methods if m not in ('allgather_c', 'p2p_c')]
     shard_bytes = g_rows * row_elems * 4
     out = {'layout': f'dest[{world}][{g_rows}][{row_elems}] f32, rank-major = concatenation of the shards', 'shard_bytes': shard_bytes,
            'chunk_rows': chunk_rows, 'backend': args.backend, 'variants': {}}
@@ -210,6 +275,7 @@ def gather_phase(args, dist, world, rank, rows, barrier_sync, gpu):
             out['variants'][m] = {
                 'pipelined_ms': round(t_pipe * 1e3, 3), 'ms': round(t_only * 1e3, 3),
                 'recv_GBps_per_gpu': round((world - 1) * shard_bytes / t_only / 1e9, 2),
+                'GBps_per_link': round(shard_bytes / t_only / 1e9, 2),      # what one peer's shard needs of one xGMI link (mesh methods: one link per peer)
                 'verified': bool(v['verified'] and v2['verified']), 'rows_sampled_per_slot': v['rows_sampled_per_slot'],
                 'memory': 'device' if (gpu is not None and (on_device or m == 'ipc')) else 'host (staging)' if gpu is not None else 'host',
             }
@@ -222,7 +288,7 @@ def gather_phase(args, dist, world, rank, rows, barrier_sync, gpu):
     ok = [m for m in methods if out['variants'].get(m, {}).get('verified')]
     head = out['variants'].get('allgather') if 'allgather' in ok else (out['variants'][ok[0]] if ok else None)
     if head is not None:
-        out.update({'ms': head['ms'], 'recv_GBps_per_gpu': head['recv_GBps_per_gpu'], 'pipelined_ms': head['pipelined_ms'],
+        out.update({'ms': head['ms'], 'recv_GBps_per_gpu': head['recv_GBps_per_gpu'], 'GBps_per_link': head['GBps_per_link'], 'pipelined_ms': head['pipelined_ms'],
                     'method': 'allgather' if 'allgather' in ok else ok[0]})
     out['verified'] = bool(methods) and len(ok) == len(methods)
     out['note'] = ('separate phase, not included in value.  ms = exchange alone (shards already computed); pipelined_ms = transforms '
@@ -243,9 +309,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-kernels', action='store_true', help='skip the untimed-for-value irfft / fused-filter measurements')
     ap.add_argument('--no-c5', action='store_true', help='skip the config-5 (f64 N=262144) entry of other_kernels')
+    ap.add_argument('--chunks', type=int, default=8, help='N = 1 only: also time the rows of configs[3] as this many sequential 8192-row launches on one GPU (0 disables)')
     ap.add_argument('--no-allgather', action='store_true')
     ap.add_argument('--allgather-timeout', type=float, default=240.0, help='seconds the separate shard-reassembly phase may take before it is abandoned (every rank then exits 3)')
-    ap.add_argument('--gather-methods', default='allgather,p2p,ipc', help='exchange methods of dsc_amd/shard.py to run and verify, in this order')
+    ap.add_argument('--gather-methods', default='allgather,p2p,ipc,allgather_c', help='exchange methods of dsc_amd/shard.py to run and verify, in this order')
     ap.add_argument('--gather-chunk-rows', type=int, default=1024, help='rows per exchange step of the chunked methods')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (gloo for the CPU dry run)')
     ap.add_argument('--dry-run', action='store_true', help='exercise the multi-process plumbing without a GPU (tests)')
@@ -304,12 +371,9 @@ def main():
 
         step()
         path = dsc.last_fft_path()
-        # parity of this very buffer against the CPU oracle (checker only; untimed)
-        from oracle import port
-        first = np.empty((4, N_FFT // 2 + 1), np.complex64)
-        B.dsc_copy_to_host(ctx, out._c_ptr, first.ctypes.data, first.nbytes)
-        want = port.rfft(x_host[:4])
-        parity = float(np.linalg.norm(first - want) / np.linalg.norm(want))
+        # parity of this very buffer (checker only; untimed): sample rows against the CPU oracle, Parseval on all rows on the device
+        with c_stdout_to_stderr():
+            parity = device_parity(dsc, B, ctx, x, out, x_host, rows, rank)
 
     if not args.dry_run and args.ramp_ms > 0:
         # clock ramp (untimed, before the W warm-up steps): the parity check above left the GPU idle
@@ -321,15 +385,23 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier_sync()
+    marks = None
     if not args.dry_run:
+        # one HIP event per step boundary on the stream the kernel is launched on (recorded, never waited for inside the loop)
+        cstream = torch.cuda.ExternalStream(B.dsc_stream(ctx))
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         B.dsc_timer_start(ctx)          # HIP events on the stream the kernel is launched on
+        marks[0].record(cstream)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         step()
+        if marks is not None:
+            marks[i + 1].record(cstream)
     if not args.dry_run:
         kernel_ms = B.dsc_timer_stop(ctx) / args.steps
     barrier_sync()
     elapsed = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)) if marks is not None else None
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if args.dry_run or args.backend == 'gloo' else 'cuda')
@@ -354,13 +426,16 @@ def main():
                 B.dsc_timer_start(ctx)
                 for _ in range(n):
                     f()
+                launches.append(n)
                 return B.dsc_timer_stop(ctx) / n
 
             ok = {}
+            launches = []
             back = dsc.empty((rows, N_FFT), dsc.Dtype.F32)
             ms_i = timed(lambda: B.dsc_irfft(ctx, out._c_ptr, back._c_ptr, -1, -1))
             ok['irfft'] = roofline_object('irfft64k_kernel', dsc.last_fft_path(), rows * BYTES_PER_ROW, ms_i, rows,
                                           f'1-D irfft f32 N={N_FFT} batch={rows} (BASELINE configs[1]), input = the spectrum the timed rfft wrote')
+            ok['irfft']['launches'] = launches[-1]
             del back
             rngf = np.random.default_rng(7)
             H = dsc.from_numpy((rngf.standard_normal(N_FFT // 2 + 1) + 1j * rngf.standard_normal(N_FFT // 2 + 1)).astype(np.complex64))
@@ -370,6 +445,7 @@ def main():
             ms_f = timed(lambda: B.dsc_filter_fft(ctx, s_half._c_ptr, H._c_ptr, y_half._c_ptr))
             ok['fused_filter'] = roofline_object('filter64k_kernel', dsc.last_fft_path(), half * N_FFT * 8, ms_f, half,
                                                  f'y = irfft(rfft(s) * H) fused, N={N_FFT} batch={half} (BASELINE configs[2]), 4 B in + 4 B out per sample, H [32769] c32 broadcast')
+            ok['fused_filter']['launches'] = launches[-1]
             del H, s_half, y_half
             if rows >= BATCH and not args.no_c5:
                 n5, b5 = 262144, 2048
@@ -389,11 +465,60 @@ def main():
                                                         f'1-D rfft f64 N={n5} batch={b5} (BASELINE configs[4])' +
                                                         ('; one launch, the four-step intermediate stays in the XCD-local L2' if k5 == 'fused_l2_kernel'
                                                          else '; two kernels, the time is their sum'))
+                ok['rfft_f64_262144']['launches'] = launches[-1]
                 del x5, X5
             ok['note'] = 'same process, same HIP-event timer, this rank only, random inputs; not included in value'
             extra['other_kernels'] = ok
         except Exception as e:
             extra['other_kernels'] = {'error': repr(e)[:200]}
+
+    # ---- N = 1 only: BASELINE configs[3]'s 65536 rows on ONE GPU as 8 sequential 8192-row launches (the 1-GPU
+    # comparison point of the 8-GPU line; a single 65536 x 65536 tensor cannot exist, `int ne`, dsc.h:104)
+    if not args.dry_run and world == 1 and args.chunks > 0 and rows == BATCH:
+        try:
+            import ctypes
+            bins = N_FFT // 2 + 1
+            ins, outs, raw = [], [], []
+            shp_i, shp_o = (ctypes.c_int * 2)(rows, N_FFT), (ctypes.c_int * 2)(rows, bins)
+            for c in range(args.chunks):
+                pi, po = B.dsc_device_alloc(ctx, rows * N_FFT * 4), B.dsc_device_alloc(ctx, rows * bins * 8)
+                if not pi or not po:
+                    raise MemoryError(f'chunk {c}: dsc_device_alloc failed')
+                raw += [pi, po]
+                ti = B.dsc_tensor_from_device_ptr(ctx, pi, rows * N_FFT * 4, 2, shp_i, int(dsc.Dtype.F32))
+                B.dsc_copy_from_host(ctx, ti, x_host.ctypes.data, x_host.nbytes)
+                ins.append(ti)
+                outs.append(B.dsc_tensor_from_device_ptr(ctx, po, rows * bins * 8, 2, shp_o, int(dsc.Dtype.C32)))
+
+            def all_chunks():
+                for ti, to in zip(ins, outs):
+                    B.dsc_rfft(ctx, ti, to, -1, -1)
+            t_end = time.perf_counter() + args.ramp_ms / 1e3
+            while time.perf_counter() < t_end:
+                all_chunks()
+                dsc.synchronize()
+            for _ in range(3):
+                all_chunks()
+            dsc.synchronize()
+            reps = max(5, args.steps // args.chunks)
+            B.dsc_timer_start(ctx)
+            for _ in range(reps):
+                all_chunks()
+            ms_c4 = B.dsc_timer_stop(ctx) / reps
+            extra['config4_on_one_gpu'] = {
+                'workload': f'1-D rfft f32 N={N_FFT}, {args.chunks * rows} rows as {args.chunks} sequential launches of {rows} rows, every chunk with its own '
+                            f'input and output buffers resident in HBM ({args.chunks * rows * BYTES_PER_ROW / 2**30:.0f} GiB)',
+                'rows': args.chunks * rows, 'chunks': args.chunks, 'ms': round(ms_c4, 4), 'ms_per_chunk': round(ms_c4 / args.chunks, 4),
+                'value': round(args.chunks * rows * N_FFT / ms_c4 / 1e6, 3), 'unit': 'GSamples/s', 'repetitions': reps,
+                'frac_of_hbm_peak': round(args.chunks * rows * BYTES_PER_ROW / (ms_c4 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                'data': 'every chunk holds the rank-0 shard (seed 1234); timing does not depend on the values',
+                'note': 'the N = 1 denominator for configs[3] (8 x MI355X, one 8192-row shard each): same rows, same launches, one GPU'}
+            for t in ins + outs:
+                B.dsc_tensor_free(ctx, t)
+            for ptr in raw:
+                B.dsc_device_free(ctx, ptr)
+        except Exception as e:
+            extra['config4_on_one_gpu'] = {'error': repr(e)[:200]}
 
     if rank == 0:
         total_samples = world * rows * N_FFT * args.steps
@@ -406,6 +531,8 @@ def main():
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 4),
+            'min_ms': round(per_step[0], 4) if per_step else None,
+            'median_ms': round(per_step[len(per_step) // 2], 4) if per_step else None,
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
@@ -418,7 +545,7 @@ def main():
         }
         if not args.dry_run:
             line['roofline'] = roofline_object('rfft64k_kernel' if path == 'r2c_64k_regs' else path, path, rows * BYTES_PER_ROW, kernel_ms, rows)
-            line['parity'] = {'rel_l2_vs_cpu_oracle': parity, 'rows_checked': 4, 'tolerance': 1e-5}
+            line['parity'] = parity
             if world == 1 and not args.no_cpu_baseline:
                 line['cpu_baseline'] = cpu_baseline()
                 line['cpu_baseline']['gpu_over_cpu'] = round(line['value'] / line['cpu_baseline']['value'], 1)

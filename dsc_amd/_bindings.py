@@ -159,4 +159,18 @@ dsc_peer_lanes = _sig('dsc_peer_lanes', c_int)
 dsc_peer_push = _sig('dsc_peer_push', c_int, _DscCtx, c_void_p, c_void_p, c_size_t, c_int)
 dsc_peer_wait = _sig('dsc_peer_wait', c_int, _DscCtx)
 
+
+class _DscCommId(Structure):           # ncclUniqueId as bytes
+    _fields_ = [('bytes', c_uint8 * 128)]
+
+
+_DscComm = c_void_p
+dsc_comm_unique_id = _sig('dsc_comm_unique_id', c_int, POINTER(_DscCommId))
+dsc_comm_init_rank = _sig('dsc_comm_init_rank', _DscComm, _DscCtx, POINTER(_DscCommId), c_int, c_int)
+dsc_comm_n_ranks = _sig('dsc_comm_n_ranks', c_int, _DscComm)
+dsc_comm_rank = _sig('dsc_comm_rank', c_int, _DscComm)
+dsc_comm_free = _sig('dsc_comm_free', None, _DscComm)
+dsc_shard_allgather = _sig('dsc_shard_allgather', c_int, _DscCtx, _DscComm, c_void_p, c_size_t, c_size_t)
+dsc_shard_exchange_rows = _sig('dsc_shard_exchange_rows', c_int, _DscCtx, _DscComm, c_void_p, c_size_t, c_size_t, c_size_t, c_size_t)
+
 EXPORTS = [n for n in dir() if n.startswith('dsc_') and n != 'dsc_api']

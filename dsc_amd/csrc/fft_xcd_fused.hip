@@ -45,7 +45,7 @@ constexpr int kPQ = 276, kPK = 17;        // row-task exchange: line pitch (valu
 #define DSC_FUSED_EXT_STORE kStream
 #endif
 #ifndef DSC_FUSED_BINS_LOAD
-#define DSC_FUSED_BINS_LOAD kCached
+#define DSC_FUSED_BINS_LOAD kStream       // round 3: -3 % on the inverse of config 5 and 1 GB less traffic (profiles/r03_l2probe.md); loads have no partial-line penalty
 #endif
 #ifndef DSC_FUSED_BINS_STORE
 #define DSC_FUSED_BINS_STORE kCached
@@ -694,9 +694,33 @@ bool launch_one(const void *in, void *out, long long rows, void *scratch, unsign
     fused_ctl *ctl = (fused_ctl *) scratch;
     C *rowsbuf = (C *) ((char *) scratch + dsc_fft_fused_l2_ctl_bytes());
     DSC_KERNEL_CHECK(hipMemsetAsync(ctl, 0, sizeof(fused_ctl), stream));
-    DSC_LAUNCH((fused_l2_kernel<R, REAL, INV, L2, NT, CAST>), dim3((unsigned) grids[dev]), dim3(NT), 0, stream, INV ? (const char *) nullptr : (const char *) in,
-               INV ? (char *) out : (char *) nullptr, INV ? (const C *) in : (const C *) nullptr, INV ? (C *) nullptr : (C *) out, rowsbuf, ctl, host_error, (int) rows,
-               cap, (const C *) tw_full, (const C *) tw_real, (R) scale, ext_pitch_b, ext_len_b, bins_pitch, bins_len);
+    // The kernel's barriers need every workgroup resident.  A COOPERATIVE launch makes the runtime guarantee that (or refuse the launch)
+    // instead of leaving it to an occupancy query and to the convention that nothing else runs on the GPU: a second context that
+    // holds part of the device then costs the fused route, not the result — the caller falls back to the two-kernel route.
+    // (DSC_FUSED_PLAIN_LAUNCH=1: the ordinary launch, for A/B timing.)
+    const char *ext_in = INV ? (const char *) nullptr : (const char *) in;
+    char *ext_out = INV ? (char *) out : (char *) nullptr;
+    const C *bins_in = INV ? (const C *) in : (const C *) nullptr;
+    C *bins_out = INV ? (C *) nullptr : (C *) out;
+    int rows_i = (int) rows, cap_i = cap;
+    static const int cap_env = getenv("DSC_FUSED_TEAMS_CAP") ? atoi(getenv("DSC_FUSED_TEAMS_CAP")) : 0;     // experiment: fewer teams = less live scratch per XCD
+    if (cap_env > 0 && cap_env < cap_i) cap_i = cap_env;
+    const C *twf = (const C *) tw_full, *twr = (const C *) tw_real;
+    R scale_r = (R) scale;
+    static const bool plain = getenv("DSC_FUSED_PLAIN_LAUNCH") != nullptr;
+    if (plain) {
+        DSC_LAUNCH((fused_l2_kernel<R, REAL, INV, L2, NT, CAST>), dim3((unsigned) grids[dev]), dim3(NT), 0, stream, ext_in, ext_out, bins_in, bins_out, rowsbuf, ctl,
+                   host_error, rows_i, cap_i, twf, twr, scale_r, ext_pitch_b, ext_len_b, bins_pitch, bins_len);
+        return true;
+    }
+    void *args[] = {&ext_in, &ext_out, &bins_in, &bins_out, &rowsbuf, &ctl, &host_error, &rows_i, &cap_i, &twf, &twr, &scale_r, &ext_pitch_b, &ext_len_b, &bins_pitch, &bins_len};
+    const hipError_t e = hipLaunchCooperativeKernel((const void *) fused_l2_kernel<R, REAL, INV, L2, NT, CAST>, dim3((unsigned) grids[dev]), dim3(NT), args, 0, stream);
+    if (e != hipSuccess) {                                          // refused (too large for what is free, or unsupported): not fatal
+        (void) hipGetLastError();
+        static bool said = false;
+        if (!said) { fprintf(stderr, "dsc: cooperative launch of the fused L2 transform refused (%s); using the two-kernel route\n", hipGetErrorString(e)); said = true; }
+        return false;
+    }
     return true;
 }
 

@@ -19,6 +19,9 @@ Three exchange methods, all filling the same layout:
   'p2p'        per chunk of rows, one group of P-1 sends + P-1 receives (batch_isend_irecv = grouped
                ncclSend/ncclRecv): every GPU talks to all peers at once, one xGMI link per peer (~S/153 GB/s),
                and chunk i travels while chunk i+1 is being transformed.
+  'allgather_c', 'p2p_c'   the same two RCCL patterns through the library's own C entry points (`dsc_comm_init_rank`,
+               `dsc_shard_allgather`, `dsc_shard_exchange_rows`: include/dsc_mi355x.h section C) — what a C++ host of the
+               reference's API calls; torch.distributed only carries the 128-byte unique id to the other ranks.
   'ipc'        per chunk, P-1 direct copies into the peers' destinations, which are mapped into this process
                through HIP IPC (dsc_ipc_export / dsc_ipc_open) — `dsc_peer_push`, one copy stream per peer,
                ordered after the transform on the context's stream by an event.  No RCCL involved: the
@@ -32,16 +35,22 @@ rank r computed from its own shard — gathered == concatenated shards, bit for 
 """
 import ctypes
 
-METHODS = ('allgather', 'p2p', 'ipc')
+METHODS = ('allgather', 'p2p', 'ipc', 'allgather_c', 'p2p_c')
 
 
 def block_partition(total_rows: int, world: int, rank: int):
     """Leading-axis block partition: rank r owns rows [start, start + count).  The first
-    `total_rows % world` ranks take one extra row, so any batch size shards."""
+    `total_rows % world` ranks take one extra row, so any batch size shards.  When the counts differ, the destination's
+    slots are `slot_rows(total_rows, world)` rows each and ShardGather is told this rank's `valid_rows`."""
     base, extra = divmod(total_rows, world)
     count = base + (1 if rank < extra else 0)
     start = rank * base + min(rank, extra)
     return start, count
+
+
+def slot_rows(total_rows: int, world: int) -> int:
+    """Rows of one slot of the [world][slot][row_elems] destination: the largest shard (ceil)."""
+    return -(-total_rows // world)
 
 
 def chunk_bounds(rows: int, chunk_rows: int):
@@ -105,15 +114,33 @@ class ShardGather:
     chunk_rows  rows per exchange step ('p2p' and 'ipc'); 'allgather' moves the whole shard in finish()
     ctx         dsc context (GPU only): its stream orders the pushes after the transforms; required for 'ipc'
     dest_ptr    raw device pointer of `dest` ('ipc' only)
+    valid_rows  rows of this rank's shard when it is shorter than the slot (uneven block_partition); default: the whole slot.
+                Whole slots travel (equal-size collectives); `valid` holds every rank's count, `verify()` and
+                `gathered_rows()` look at the valid rows only.
+
+    Every rank must pass the same slot shape and chunking: checked here with one all_gather_object, so that a mismatch
+    raises on every rank instead of mis-laying rows or hanging a collective.
     """
 
-    def __init__(self, dist, dest, chunk_rows, method='p2p', ctx=None, dest_ptr=None):
+    def __init__(self, dist, dest, chunk_rows, method='p2p', ctx=None, dest_ptr=None, valid_rows=None):
         if method not in METHODS:
             raise ValueError(f'method must be one of {METHODS}')
         self.dist, self.dest, self.method, self.ctx = dist, dest, method, ctx
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         assert dest.dim() == 3 and dest.shape[0] == self.world and dest.is_contiguous()
         self.rows, self.row_elems = int(dest.shape[1]), int(dest.shape[2])
+        mine = self.rows if valid_rows is None else int(valid_rows)
+        if not 0 <= mine <= self.rows:
+            raise ValueError(f'valid_rows = {mine} outside the slot of {self.rows} rows')
+        said = [None] * self.world
+        if self.world > 1:
+            dist.all_gather_object(said, (self.rows, self.row_elems, int(chunk_rows), mine))
+        else:
+            said[0] = (self.rows, self.row_elems, int(chunk_rows), mine)
+        if any(x[:3] != said[0][:3] for x in said):
+            raise ValueError('ShardGather: (slot rows, row elements, chunk rows) differ between ranks: ' + repr([x[:3] for x in said]) +
+                             ' — size the slots with shard.slot_rows() and pass valid_rows for the shorter shards')
+        self.valid = [x[3] for x in said]
         self.chunks = chunk_bounds(self.rows, chunk_rows)
         self.on_gpu = dest.is_cuda
         self._works = []
@@ -125,6 +152,12 @@ class ShardGather:
             self._stream = torch.cuda.ExternalStream(B.dsc_stream(ctx))
         self._mapped = None
         self._failed = None
+        self._comm = None
+        if method in ('allgather_c', 'p2p_c'):
+            if not (self.on_gpu and ctx is not None and dest_ptr):
+                raise ValueError(f"'{method}' needs a device destination, its raw pointer and the dsc context")
+            self._own_ptr = dest_ptr
+            self._open_comm()
         if method == 'ipc':
             if not (self.on_gpu and ctx is not None and dest_ptr):
                 raise ValueError("'ipc' needs a device destination, its raw pointer and the dsc context")
@@ -165,6 +198,33 @@ class ShardGather:
         self._mapped = mapped
         self._own_ptr = dest_ptr
 
+    # ---- the library's own RCCL communicator (include/dsc_mi355x.h section C)
+    def _open_comm(self):
+        """Rank 0 makes the unique id, torch.distributed's object broadcast ships it, every rank joins; a rank that fails
+        says so to all before anybody raises."""
+        from . import _bindings as B
+        box = [None]
+        if self.rank == 0:
+            cid = B._DscCommId()
+            box[0] = bytes(cid.bytes) if B.dsc_comm_unique_id(ctypes.byref(cid)) == 0 else None
+        if self.world > 1:
+            self.dist.broadcast_object_list(box, src=0)
+        if box[0] is None:
+            raise RuntimeError('dsc_comm_unique_id failed on rank 0 (RCCL not loadable?)')
+        cid = B._DscCommId()
+        ctypes.memmove(cid.bytes, box[0], 128)
+        comm = B.dsc_comm_init_rank(self.ctx, ctypes.byref(cid), self.world, self.rank)
+        said = [None] * self.world
+        if self.world > 1:
+            self.dist.all_gather_object(said, bool(comm))
+        else:
+            said[0] = bool(comm)
+        if not all(said):
+            if comm:
+                B.dsc_comm_free(comm)
+            raise RuntimeError(f'dsc_comm_init_rank failed on rank(s) {[r for r, ok in enumerate(said) if not ok]}')
+        self._comm = comm
+
     def _under_ctx_stream(self):
         import contextlib
         import torch
@@ -175,7 +235,12 @@ class ShardGather:
         everything enqueued so far on the context's stream."""
         r0, n = self.chunks[i]
         self._pushed += 1
-        if self.method == 'allgather' or self.world == 1:
+        if self.method in ('allgather', 'allgather_c') or self.world == 1:
+            return
+        if self.method == 'p2p_c':
+            from . import _bindings as B
+            if B.dsc_shard_exchange_rows(self.ctx, self._comm, self._own_ptr, self.rows, self.row_elems * 4, r0, n) != 0:
+                self._failed = self._failed or 'dsc_shard_exchange_rows failed'
             return
         if self.method == 'ipc':
             from . import _bindings as B
@@ -204,6 +269,13 @@ class ShardGather:
         rank's dest holds all shards."""
         assert self._pushed == len(self.chunks), 'finish() before every chunk was pushed'
         dist = self.dist
+        if self.method == 'allgather_c':                      # also with one rank: the C entry point and RCCL are exercised for real
+            from . import _bindings as B
+            if B.dsc_shard_allgather(self.ctx, self._comm, self._own_ptr, self.rows, self.row_elems * 4) != 0:
+                self._failed = self._failed or 'dsc_shard_allgather failed'
+        if self.method in ('allgather_c', 'p2p_c'):
+            from . import _bindings as B
+            B.dsc_synchronize(self.ctx)                       # the collectives were enqueued on the context's stream
         if self.world > 1:
             if self.method == 'allgather':
                 with self._under_ctx_stream():
@@ -219,9 +291,12 @@ class ShardGather:
         if self.on_gpu:
             import torch
             torch.cuda.synchronize()
+            if self.ctx is not None:                          # also the library's own check of its deferred device-side errors
+                from . import _bindings as B
+                B.dsc_synchronize(self.ctx)
         self._pushed = 0
         if self.world > 1:
-            if self.method == 'ipc':                          # the barrier doubles as the agreement on a one-sided failure
+            if self.method in ('ipc', 'allgather_c', 'p2p_c'):   # the barrier doubles as the agreement on a one-sided failure
                 said = [None] * self.world
                 dist.all_gather_object(said, self._failed)
                 self._failed = None
@@ -234,6 +309,10 @@ class ShardGather:
             raise RuntimeError(msg)
 
     def close(self):
+        if self._comm is not None:
+            from . import _bindings as B
+            B.dsc_comm_free(self._comm)
+            self._comm = None
         if self._mapped is not None:
             from . import _bindings as B
             self.dist.barrier()                               # nobody is still writing into a mapping
@@ -243,22 +322,28 @@ class ShardGather:
             self._mapped = None
 
     # ---- proof of reassembly
-    def _digest(self, shard):
-        """(position-weighted checksum of the whole shard, sample rows) — integer arithmetic on the raw bits."""
+    def _digest(self, shard, valid):
+        """(position-weighted checksum of the shard's valid rows, sample rows) — integer arithmetic on the raw bits."""
         import torch
-        bits = shard.view(torch.int32)
+        bits = shard.view(torch.int32)[:valid]
         row_sums = torch.sum(bits, dim=1, dtype=torch.int64)
-        weights = torch.arange(1, self.rows + 1, dtype=torch.int64, device=shard.device)
+        weights = torch.arange(1, valid + 1, dtype=torch.int64, device=shard.device)
         cks = int(torch.sum(row_sums * weights).item())       # int64 wrap-around is deterministic
-        idx = sorted({r0 for r0, _ in self.chunks} | {r0 + n - 1 for r0, n in self.chunks})
+        idx = sorted(i for i in ({r0 for r0, _ in self.chunks} | {r0 + n - 1 for r0, n in self.chunks}) if i < valid)
         samples = bits[idx].cpu()
         return cks, idx, samples
+
+    def gathered_rows(self):
+        """The concatenation of the shards' valid rows, rank order — a copy; equals dest.view(-1, row_elems) when every
+        shard fills its slot."""
+        import torch
+        return torch.cat([self.dest[r, :self.valid[r]] for r in range(self.world)], dim=0)
 
     def verify(self):
         """Every rank checks every slot of its dest against what the owning rank says its shard is.
         Returns {'verified': bool, ...}; never raises on a mismatch (the caller reports it)."""
         import torch
-        mine = self._digest(self.dest[self.rank])
+        mine = self._digest(self.dest[self.rank], self.valid[self.rank])
         every = [None] * self.world
         if self.world > 1:
             self.dist.all_gather_object(every, mine)
@@ -266,7 +351,7 @@ class ShardGather:
             every[0] = mine
         bad = []
         for r in range(self.world):
-            cks, idx, samples = self._digest(self.dest[r])
+            cks, idx, samples = self._digest(self.dest[r], self.valid[r])
             want_cks, want_idx, want_samples = every[r]
             if cks != want_cks or idx != want_idx or not torch.equal(samples, want_samples):
                 bad.append(r)

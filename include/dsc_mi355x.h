@@ -256,6 +256,27 @@ int   dsc_peer_push(dsc_ctx *ctx, void *dst, const void *src, size_t nbytes, int
 /* Host waits until every push on every lane has landed (then exchange a barrier before peers read). */
 int   dsc_peer_wait(dsc_ctx *ctx);
 
+/* The collective north_star names: an RCCL communicator (one rank per process and GPU) and the all-gather that reassembles
+ * the output, callable from a C / C++ host (the reference's C++ users, dsc/api/dsc_api.h:24-34) — no Python required.
+ * RCCL is loaded on first use (dlopen); a process that never calls these never maps it.  All calls report failures
+ * (-1 / NULL + a message on stderr) instead of exiting: the caller decides what a missing peer means.
+ *   bootstrap: rank 0 calls dsc_comm_unique_id, the host ships the 128 bytes to the other ranks by its own means, every rank
+ *   calls dsc_comm_init_rank (collective: returns once all n_ranks have called it). */
+typedef struct dsc_comm dsc_comm;
+typedef struct dsc_comm_id { unsigned char bytes[128]; } dsc_comm_id;      /* ncclUniqueId as bytes */
+int       dsc_comm_unique_id(dsc_comm_id *out);
+dsc_comm *dsc_comm_init_rank(dsc_ctx *ctx, const dsc_comm_id *id, int n_ranks, int rank);
+int       dsc_comm_n_ranks(const dsc_comm *comm);
+int       dsc_comm_rank(const dsc_comm *comm);
+void      dsc_comm_free(dsc_comm *comm);
+/* ONE in-place ncclAllGather on the persistent destination dest[n_ranks][rows][row_bytes]: this rank's shard already lies in
+ * slot dest[rank] (its transform wrote it there through dsc_tensor_from_device_ptr views).  Enqueued on the context's stream,
+ * i.e. ordered after the transforms enqueued so far; dsc_synchronize waits for it.  Every rank passes the same rows / row_bytes. */
+int       dsc_shard_allgather(dsc_ctx *ctx, dsc_comm *comm, void *dest, size_t rows, size_t row_bytes);
+/* Rows [row0, row0 + n_rows) of every slot in one group of P-1 ncclSend + P-1 ncclRecv (every GPU talks to all peers at once,
+ * one xGMI link per peer): the chunk-wise form, so that chunk i travels while chunk i+1 is transformed.  Same ordering rules. */
+int       dsc_shard_exchange_rows(dsc_ctx *ctx, dsc_comm *comm, void *dest, size_t rows, size_t row_bytes, size_t row0, size_t n_rows);
+
 #ifdef __cplusplus
 }
 #endif

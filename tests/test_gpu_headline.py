@@ -923,6 +923,18 @@ def test_every_power_of_two_length(dsc, dt):
     assert need <= set(paths), paths.keys()
 
 
+def test_shard_gather_through_the_c_collectives_one_rank():
+    """dsc_amd/shard.py's 'allgather_c' and 'p2p_c' (the library's own RCCL entry points, include/dsc_mi355x.h section C) with a
+    one-rank group: the transform writes its slot in place, the C all-gather runs for real, verify() passes
+    (tools/check_c_collectives.py, its own process like the other torch.cuda users)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_c_collectives.py')], capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0 and 'OK' in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_rccl_sees_arena_memory_one_rank():
     """bench.py's all-gather phase hands RCCL zero-copy views of arena memory: with a one-rank NCCL (= RCCL) group on the
     test box's single GPU the view goes through all_gather_into_tensor, all_reduce and barrier and comes back intact

@@ -90,6 +90,60 @@ def _bad_slots(res, rank):
     return [x for x in res if x[0] == rank][0][3]['bad_slots_on_this_rank']
 
 
+def _uneven_worker(rank, world, port, method, total, row_elems, chunk_rows, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch
+    import torch.distributed as dist
+    from dsc_amd import shard
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        whole = shard_of(0, total, row_elems)                       # the global array; rank r transforms its block of it
+        start, count = shard.block_partition(total, world, rank)
+        rows = shard.slot_rows(total, world)
+        dest = torch.full((world, rows, row_elems), -1.0, dtype=torch.float32)
+        g = shard.ShardGather(dist, dest, chunk_rows, method=method, valid_rows=count)
+        for i, (r0, n) in enumerate(g.chunks):
+            m = max(0, min(n, count - r0))
+            dest[rank, r0:r0 + m] = torch.from_numpy(whole[start + r0:start + r0 + m])
+            g.push(i)
+        g.finish()
+        equal = bool(np.array_equal(g.gathered_rows().numpy(), whole))
+        v = g.verify()
+        # a rank that sizes its slot from its OWN count (the mistake the agreement check exists for) must raise everywhere
+        raised = False
+        try:
+            shard.ShardGather(dist, torch.zeros((world, count if rank else rows, row_elems)), chunk_rows, method=method)
+        except ValueError:
+            raised = True
+        q.put((rank, equal, v, g.valid, raised))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('method', ['p2p', 'allgather'])
+def test_uneven_shards_keep_their_rows(method):
+    """11 rows over 3 ranks = 4 + 4 + 3: slots of ceil(11 / 3) rows, the short shard says how many of its rows count;
+    gathered valid rows == the global array on every rank; mismatched slot shapes raise on every rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, 3, port, method, 11, 6, 3, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, equal, v, valid, raised in out:
+        assert valid == [4, 4, 3]
+        assert equal, f'rank {rank}: gathered valid rows != global array'
+        assert v['verified'] is True
+        assert raised, f'rank {rank}: mismatched slot shapes went unnoticed'
+
+
 def test_block_partition_covers_every_row_once():
     sys.path.insert(0, ROOT)
     from dsc_amd import shard
@@ -99,4 +153,5 @@ def test_block_partition_covers_every_row_once():
         for (s0, c0), (s1, _) in zip(spans, spans[1:]):
             assert s0 + c0 == s1
     assert shard.block_partition(65536, 8, 3) == (3 * 8192, 8192)     # config 4: 8 shards of config 2
+    assert shard.slot_rows(11, 3) == 4 and shard.slot_rows(65536, 8) == 8192
     assert shard.chunk_bounds(50, 16) == [(0, 16), (16, 16), (32, 16), (48, 2)]

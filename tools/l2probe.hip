@@ -238,6 +238,109 @@ __global__ __launch_bounds__(T, 2) void probe_split(params p) {
     if (sink == 0x12345u) p.errs[3] = sink;
 }
 
+
+// The sliced exchange as a PIPELINE: a row's scratch passes in K slices through a ring of S slots per team (slot = 1/K row).
+// Every workgroup writes its 16/K elements of every slice; slice s is consumed by TS/K of the workgroups (16 elements per thread),
+// LAG slices after they wrote it, so that a slice settles in the L2 while its consumers already write the next one.  Counters
+// per slot (cumulative): W = workgroups that have written, R = consumers that have read.
+template<int K, int S, int LAG>
+__global__ __launch_bounds__(T, 2) void probe_pipe(params p) {
+    extern __shared__ unsigned lds[];
+    static_assert(K % S == 0 && LAG < S, "ring");
+    const int tid = threadIdx.x, TS = p.ts;
+    constexpr int EK = E / K;
+    if (tid == 0) {
+        const unsigned x = xcc_id() & 7u;
+        lds[0] = x;
+        lds[1] = atomicAdd(&p.tickets[64 * x], 1u);
+        lds[2] = 0;
+    }
+    __syncthreads();
+    if ((int) lds[1] >= TS * p.tpx) { if (tid == 0) atomicAdd(p.errs + 1, 1u); return; }
+    const int xcc = (int) lds[0], lteam = (int) lds[1] / TS, q = (int) lds[1] % TS;
+    const int team = xcc + 8 * lteam;
+    const int CPS = TS / K, sc = q / CPS, cidx = q % CPS;         // consumers per slice; my slice; my place among its consumers
+    const int row_e = kTaskE * TS, row_b = row_e * 16, slot_b = TS * T * EK * 16;
+    u4 *ring = p.scratch + ((size_t) xcc * 64 * (2 << 20) + (size_t) lteam * S * slot_b) / 16;
+    unsigned *cW = p.bars + 1024 * team, *cR = cW + 512;          // counter of slot i at [32 i]: one 128-B line each
+    const int l8 = tid & 7, p8 = tid >> 3, l16 = tid & 15, p16 = tid >> 4;
+    u4 cur[E], nxt[E];
+    auto request = [&](u4 (&dst)[E], int row) {
+        if (p.no_in) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) dst[e] = u4{(unsigned) row, (unsigned) ((q + TS * (e * (T / 8) + p8)) * 8 + l8), 0x5a5a5a5au, 0u};
+            return;
+        }
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *) (p.in + (size_t) row * row_e), 0, row_b, 0x00020000);
+#pragma unroll
+        for (int e = 0; e < E; ++e) dst[e] = __builtin_amdgcn_raw_buffer_load_b128(r, ((q + TS * (e * (T / 8) + p8)) * 8 + l8) * 16, 0, 2);
+    };
+    auto wait_for = [&](unsigned *c, unsigned need) {
+        if (tid == T - 1) {
+            unsigned spins = 0;
+            while ((int) (l2_read(c) - need) < 0) {
+                if (p.delay) __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 17)) { atomicAdd(p.errs + 2, 1u); lds[2] = 1; break; }
+            }
+        }
+        lds_only_barrier();
+    };
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void *) ring, 0, S * slot_b, 0x00020000);
+    const int stride = 8 * p.tpx;
+    int row = team;
+    if (row < p.rows) request(cur, row);
+    unsigned bad = 0, sink = 0;
+    for (int it = 0; row < p.rows; row += stride, ++it) {
+        const int next = row + stride;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *) (p.out + (size_t) row * row_e), 0, row_b, 0x00020000);
+        auto consume = [&]() {
+            const int slot = sc % S;
+            const unsigned use = (unsigned) (it * (K / S) + sc / S);
+            wait_for(cW + 32 * slot, (use + 1) * (unsigned) TS);
+            u4 got[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) got[e] = __builtin_amdgcn_raw_buffer_load_b128(rr, slot * slot_b + ((cidx + CPS * (e * (T / 16) + p16)) * 16 + l16) * 16, 0, 16);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int sl = (cidx + CPS * (e * (T / 16) + p16)) * 16 + l16;
+                const int wq = sl / (T * EK), we = (sl % (T * EK)) / T, wt = sl % T;
+                const unsigned j = (unsigned) ((wq + TS * ((sc * EK + we) * (T / 8) + (wt >> 3))) * 8 + (wt & 7));
+                bad += (got[e].x != (unsigned) row) | (got[e].y != j);
+            }
+            // (the loads have landed: their values were compared)
+            lds_only_barrier();
+            if (tid == T - 1) l2_add(cR + 32 * slot);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int so = (q + TS * (e * (T / 16) + p16)) * 16 + l16;
+                if (p.no_out) sink ^= got[e].z + got[e].w;
+                else __builtin_amdgcn_raw_buffer_store_b128(got[e], ro, so * 16, 0, 2);
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            const int slot = s % S;
+            const unsigned use = (unsigned) (it * (K / S) + s / S);
+            if (it > 0 || s >= S) wait_for(cR + 32 * slot, use * (unsigned) CPS);
+            if (lds[2]) return;
+#pragma unroll
+            for (int e = 0; e < EK; ++e) __builtin_amdgcn_raw_buffer_store_b128(cur[s * EK + e], rr, slot * slot_b + (q * T * EK + e * T + tid) * 16, 0, 0);
+            if (s == K - 1 && next < p.rows) request(nxt, next);
+            // the stores of this slice are in the L2 (the next row's loads, issued after them, may still be in flight)
+            if (s == K - 1 && next < p.rows && !p.no_in) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(E) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_only_barrier();
+            if (tid == T - 1) l2_add(cW + 32 * slot);
+            if (s == (sc + LAG < K - 1 ? sc + LAG : K - 1)) { consume(); if (lds[2]) return; }
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) cur[e] = nxt[e];
+    }
+    if (bad) atomicAdd(p.errs, bad);
+    if (sink == 0x12345u) p.errs[3] = sink;
+}
+
 struct state { u4 *in, *out, *scratch; unsigned *bars, *tickets, *errs; int row_e; bool pmc; };
 
 template<int IPOL, int OPOL, int APOL, int RPOL>
@@ -309,12 +412,45 @@ void run_split(state &s, int ts, int tpx, int no_in = 0, int no_out = 0, int pol
     fflush(stdout);
 }
 
+template<int K, int S, int LAG>
+void run_pipe(state &s, int ts, int tpx, int no_in = 0, int no_out = 0, int poll_sleep = 0) {
+    const int row_e = kTaskE * ts;
+    if (s.row_e != row_e) {
+        hipLaunchKernelGGL(init_rows, dim3((unsigned) (kTotalE / 256)), dim3(256), 0, 0, s.in, kTotalE, row_e);
+        s.row_e = row_e;
+    }
+    params p{s.in, s.out, s.scratch, s.bars, s.tickets, s.errs, (int) (kTotalE / row_e), ts, tpx, poll_sleep, no_in, no_out, 0, 0, 0, 16};
+    const int wg_per_xcd = ts * tpx, wpc = (wg_per_xcd + 31) / 32;
+    const int lds = wpc == 1 ? 96 * 1024 : 48 * 1024;
+    auto k = probe_pipe<K, S, LAG>;
+    CK(hipFuncSetAttribute((const void *) k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipEvent_t a, c; CK(hipEventCreate(&a)); CK(hipEventCreate(&c));
+    float best = 1e30f;
+    for (int r = 0; r < (s.pmc ? 1 : 4); ++r) {
+        CK(hipMemsetAsync(s.bars, 0, 64 * 1024 * 4, 0));
+        CK(hipMemsetAsync(s.tickets, 0, 8 * 64 * 4, 0));
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL(k, dim3(8 * wg_per_xcd), dim3(T), lds, 0, p);
+        CK(hipGetLastError());
+        CK(hipEventRecord(c)); CK(hipEventSynchronize(c));
+        float ms; CK(hipEventElapsedTime(&ms, a, c)); if (ms < best) best = ms;
+    }
+    unsigned errs[4];
+    CK(hipMemcpy(errs, s.errs, sizeof errs, hipMemcpyDeviceToHost));
+    CK(hipMemset(s.errs, 0, sizeof errs));
+    static int n = 0;
+    const double slot_kib = ts * 64.0 / K;
+    printf("variant %2d: pipe K=%d S=%d lag %d slot %5.0f KiB  teams/XCD %2d  live %5.2f MiB%s%s poll-sleep %d delay 0  %8.3f ms  %6.0f GB/s  stale %u uneven %u timeouts %u\n", n++, K, S, LAG,
+           slot_kib, tpx, tpx * S * slot_kib / 1024.0, no_in ? " NO-IN" : "", no_out ? " NO-OUT" : "", poll_sleep, best, 2.0 * kTotalE * 16 / best / 1e6, errs[0], errs[1], errs[2]);
+    fflush(stdout);
+}
+
 int main() {
     state s;
     s.pmc = getenv("L2P_PMC") != nullptr;
     CK(hipMalloc(&s.in, (size_t) kTotalE * 16)); CK(hipMalloc(&s.out, (size_t) kTotalE * 16));
     CK(hipMalloc(&s.scratch, (size_t) 8 * 64 * (2 << 20)));
-    CK(hipMalloc(&s.bars, 256 * 64 * 4)); CK(hipMalloc(&s.tickets, 8 * 64 * 4)); CK(hipMalloc(&s.errs, 16));
+    CK(hipMalloc(&s.bars, 64 * 1024 * 4)); CK(hipMalloc(&s.tickets, 8 * 64 * 4)); CK(hipMalloc(&s.errs, 16));
     CK(hipMemset(s.errs, 0, 16));
     s.row_e = 0;
     const char *only = getenv("L2P_ONLY");
@@ -404,6 +540,19 @@ int main() {
             run_split<1>(s, 8, 8, no, no); run_split<2>(s, 8, 8, no, no); run_split<4>(s, 8, 8, no, no);
         }
         run_split<2>(s, 32, 2, 1, 1, 0); run_split<4>(s, 32, 2, 1, 1, 0); run_split<2>(s, 32, 2, 0, 0, 0); run_split<4>(s, 32, 2, 0, 0, 0);
+    }
+    if (want("E8")) {
+        printf("# E8: the sliced exchange as a pipeline (K slices through a ring of S slots per team, consumers LAG slices behind)\n");
+        for (int no : {1, 0}) {
+            run_pipe<4, 1, 0>(s, 32, 2, no, no);
+            run_pipe<4, 2, 0>(s, 32, 2, no, no); run_pipe<4, 2, 1>(s, 32, 2, no, no);
+            run_pipe<8, 2, 0>(s, 32, 2, no, no); run_pipe<8, 2, 1>(s, 32, 2, no, no);
+            run_pipe<8, 4, 1>(s, 32, 2, no, no); run_pipe<8, 4, 2>(s, 32, 2, no, no); run_pipe<8, 4, 3>(s, 32, 2, no, no);
+            run_pipe<16, 4, 1>(s, 32, 2, no, no); run_pipe<16, 4, 3>(s, 32, 2, no, no); run_pipe<16, 8, 3>(s, 32, 2, no, no); run_pipe<16, 8, 7>(s, 32, 2, no, no);
+            run_pipe<8, 2, 1>(s, 32, 1, no, no); run_pipe<8, 4, 3>(s, 32, 1, no, no); run_pipe<16, 8, 7>(s, 32, 1, no, no);
+            run_pipe<4, 2, 1>(s, 16, 4, no, no); run_pipe<8, 2, 1>(s, 16, 4, no, no); run_pipe<8, 4, 3>(s, 16, 4, no, no);
+            run_pipe<4, 2, 1>(s, 8, 8, no, no); run_pipe<8, 2, 1>(s, 8, 8, no, no);
+        }
     }
     return 0;
 }

@@ -11,7 +11,7 @@ def counters(name, factor):
     rows = []
     for f in glob.glob(f'{out}/pmc_{name}/**/*counter_collection.csv', recursive=True):
         for n, r in enumerate(csv.DictReader(open(f))):
-            if ('probe<' in r['Kernel_Name'] or 'probe_split<' in r['Kernel_Name']) and r['Counter_Name'] == name:
+            if ('probe<' in r['Kernel_Name'] or 'probe_split<' in r['Kernel_Name'] or 'probe_pipe<' in r['Kernel_Name']) and r['Counter_Name'] == name:
                 rows.append((int(r.get('Dispatch_Id', n)), float(r['Counter_Value']) * factor * 1024 / 1e9))
     return [v for _, v in sorted(rows)]
 
