@@ -128,9 +128,17 @@ __device__ __forceinline__ void cols_passes(cpx<R> (&v)[32], R *plane, const cpx
 // in / out: tensor base; the transformed axis has in_len valid input elements (reals for R2C_PACKED, bins for C2R, complex
 // otherwise; the rest of the transform length reads as zero: dsc.cpp:1990-1998, 2125-2133, 2149-2157) and a pitch of `inner`
 // elements between consecutive elements; in_axis / out_axis = the axis lengths of the two tensors (slice pitch = axis * inner).
+//
+// Round 3.  (1) The three-pass forms (L = 2048, 4096: one workgroup fills a CU) are PERSISTENT and software pipelined like the
+// 65536-point kernels: a workgroup walks tiles blockIdx.x, + gridDim.x, ...; the next tile's loads are issued into registers
+// the current tile has finished with, ahead of (half of) its stores, so that a CU's load, compute and store phases overlap.
+// (2) The inverse packed-real pre-pass handles every pair (k, L - k) ONCE: a thread loads its lower 16 bins AND their partners
+// (rows L - k: the same 32 row loads as its own upper half), computes Z[k] and Z[L - k] together and hands Z[L - k] to its owner
+// through the staging plane — half the arithmetic, one exchange instead of two, and no second 32-value array (the old form
+// spilled 14 - 35 registers).
 template<typename R, int B, bool TWO, int CW, int MODE, bool INV>
 __global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO, CW>::WAVES_PER_EU)) void fft_cols_kernel(
-    const void *__restrict__ in, void *__restrict__ out, int inner, int tiles_per_slice, int in_axis, int in_len, int out_axis,
+    const void *__restrict__ in, void *__restrict__ out, int inner, int tiles_per_slice, int n_tiles, int in_axis, int in_len, int out_axis,
     const cpx<R> *__restrict__ tw_full, const cpx<R> *__restrict__ tw_real, R scale) {
     using C = cpx<R>;
     using cfg = cols_cfg<R, B, TWO, CW>;
@@ -139,155 +147,237 @@ __global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO,
     constexpr int IB = (MODE == DSC_MODE_R2C_PACKED || MODE == DSC_MODE_R2C_CAST) ? RB : CB;       // bytes per input element
     constexpr int OB = MODE == DSC_MODE_C2R_PACKED ? RB : CB;       // bytes per output element
     constexpr int kOut = 0x7f000000;                                // an offset past every descriptor range: reads 0, stores dropped
+    constexpr bool PIPE = !TWO;                                     // persistent, next tile requested ahead of the stores
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     R *plane = (R *) lds_raw;
     C *wtab = (C *) (plane + cfg::PLANE);
 
-    const int tid = threadIdx.x;
-    const int c = tid % CW, t = tid / CW;
-    const int slice = blockIdx.x / tiles_per_slice;
-    const int col = (blockIdx.x - slice * tiles_per_slice) * CW + c;
-    const bool live = col < inner;
+    for (int i = threadIdx.x; i < cfg::TABLE; i += NT) wtab[i] = tw_full[(long long) i * cfg::TABLE_STRIDE];
+    // Everything derived from the thread id is loop invariant: hipcc hoists it out of the persistent loop (dozens of addresses) and
+    // then spills.  Each phase therefore rebuilds (t, c) from an opaque copy of the id, so that nothing outlives its phase.
+    auto tid_now = [&]() { int x = (int) threadIdx.x; asm volatile("" : "+v"(x)); return x; };
 
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
-        (void *) ((const char *) in + (size_t) slice * in_axis * inner * IB), 0, in_len * inner * IB, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
-        (void *) ((char *) out + (size_t) slice * out_axis * inner * OB), 0, out_axis * inner * OB, 0x00020000);
-
-    for (int i = tid; i < cfg::TABLE; i += NT) wtab[i] = tw_full[(long long) i * cfg::TABLE_STRIDE];
-
-    // ---- load: v[j1] = z[T j1 + t]
-    C v[32];
-    // (Measured and dropped: moving the real rows 8 bytes per lane — the two lanes of a column pair splitting the two rows and a
-    // DPP swap putting (re, im) back together — is within +-7 % of this 4-byte form, better at some lengths and worse at others.)
-    if constexpr (MODE == DSC_MODE_R2C_PACKED) {                    // z[m] = (x[2m], x[2m + 1]): two rows of the axis
-        const int voff = live ? (2 * t * inner + col) * RB : kOut;
-        const int row_b = inner * RB, step = 2 * T * inner * RB;
+    // descriptor of a tile's input slice (wave uniform) and a lane's column in it; a tile past the end reads zeros
+    auto in_rsrc = [&](int tile) {
+        const int slice = tile / tiles_per_slice;
+        return __builtin_amdgcn_make_buffer_rsrc((void *) ((const char *) in + (size_t) slice * in_axis * inner * IB), 0, tile < n_tiles ? in_len * inner * IB : 0, 0x00020000);
+    };
+    auto col_of = [&](int tile, int c) { return (tile - (tile / tiles_per_slice) * tiles_per_slice) * CW + c; };
+    // the loads of one tile, rows [J0, J0 + N) of the 32 a thread holds (see the modes below); C2R: dst[j] = Y[T j + t] for j < 16,
+    // dst[16 + j] = its partner Y[L - T j - t]
+    auto request = [&](auto &dst, auto j0_tag, auto n_tag, int tile) {
+        constexpr int J0 = decltype(j0_tag)::value, N = decltype(n_tag)::value;
+        const __amdgpu_buffer_rsrc_t rin = in_rsrc(tile);
+        const int tid = tid_now(), c = tid % CW, t = tid / CW;
+        const int col = col_of(tile, c);
+        const bool live = col < inner;
+        if constexpr (MODE == DSC_MODE_R2C_PACKED) {                // z[m] = (x[2m], x[2m + 1]): two rows of the axis
+            const int voff = live ? (2 * t * inner + col) * RB : kOut;
+            const int row_b = inner * RB, step = 2 * T * inner * RB;
 #pragma unroll
-        for (int j1 = 0; j1 < 32; ++j1) {
-            const cpx<R> a = buf_load_real<kStream>(rin, voff, j1 * step, R{}), b = buf_load_real<kStream>(rin, voff, j1 * step + row_b, R{});
-            v[j1] = C{a.x, b.x};
-        }
-    } else if constexpr (MODE == DSC_MODE_R2C_CAST) {               // dsc_fft / dsc_ifft of a real tensor: widened while loading
-        const int voff = live ? (t * inner + col) * RB : kOut;
-        const int step = T * inner * RB;
-#pragma unroll
-        for (int j1 = 0; j1 < 32; ++j1) v[j1] = buf_load_real<kStream>(rin, voff, j1 * step, R{});
-    } else {
-        const int voff = live ? (t * inner + col) * CB : kOut;
-        const int step = T * inner * CB;
-#pragma unroll
-        for (int j1 = 0; j1 < 32; ++j1) v[j1] = buf_load<kStream>(rin, voff, j1 * step, R{});
-    }
-
-    R *stage = plane + c;                                           // stage[k * CW] = component of bin k of this column
-    if constexpr (MODE == DSC_MODE_C2R_PACKED) {
-        // Z[k] = (a + conj b)/2 + wq (a - conj b), a = Y[k], b = Y[L-k], wq = (i/2) conj(W_2L^k), k = T j1 + t (dsc_fft.h:194-228)
-        const C wbase = tw_real[t];
-        C yl = C{(R) 0, (R) 0};
-        if (t == 0) {                                               // bins 0 and L: real parts only (dsc_fft.h:227-228)
-            yl = buf_load<kStream>(rin, live ? col * CB : kOut, L * inner * CB, R{});
-            v[0].y = (R) 0;
-            yl.y = (R) 0;
-        }
-        R dx[32];
-        R *up = stage + t * CW;
-        const R *dn = stage + ((L - 31 * T) - t) * CW;
-#pragma unroll
-        for (int j1 = 0; j1 < 32; ++j1) up[T * j1 * CW] = v[j1].x;
-        if (t == 0) stage[L * CW] = yl.x;
-        lds_barrier();
-#pragma unroll
-        for (int j1 = 0; j1 < 32; ++j1) {
-            const R bx = dn[T * (31 - j1) * CW];
-            dx[j1] = v[j1].x - bx;
-            v[j1].x = v[j1].x + bx;
-        }
-        lds_barrier();
-#pragma unroll
-        for (int j1 = 0; j1 < 32; ++j1) up[T * j1 * CW] = v[j1].y;
-        if (t == 0) stage[L * CW] = yl.y;
-        lds_barrier();
-#pragma unroll
-        for (int j1 = 0; j1 < 32; ++j1) {
-            const R by = dn[T * (31 - j1) * CW];
-            const C w = cmul(wbase, C{(R) root64_re(j1), (R) root64_im(j1)});      // W_2L^{t + T j1} = W_2L^t W_64^{j1}
-            const R wqx = (R) 0.5 * w.y, wqy = (R) 0.5 * w.x;
-            const R sy = v[j1].y - by, dy = v[j1].y + by;
-            const R zx = (R) 0.5 * v[j1].x + (dx[j1] * wqx - dy * wqy);
-            const R zy = (R) 0.5 * sy + (dx[j1] * wqy + dy * wqx);
-            v[j1] = C{zx, zy};
-        }
-    }
-    __syncthreads();                // twiddle table visible; staging reads done before the plane is reused
-
-    cols_passes<R, B, TWO, CW, INV>(v, plane, wtab, tw_full, t, c);
-
-    if constexpr (MODE == DSC_MODE_C2C || MODE == DSC_MODE_R2C_CAST) {
-        const int voff = live ? (t * inner + col) * CB : kOut;
-        const int step = inner * CB;
-#pragma unroll
-        for (int i = 0; i < CPT; ++i)
-#pragma unroll
-            for (int p = 0; p < B; ++p) {
-                const C r = v[i * B + p];
-                buf_store<kStream>(C{r.x * scale, r.y * scale}, rout, voff, (T * i + COLS * brev(p, LOGB)) * step);
+            for (int j = 0; j < N; ++j) {
+                const cpx<R> a = buf_load_real<kStream>(rin, voff, (J0 + j) * step, R{}), b = buf_load_real<kStream>(rin, voff, (J0 + j) * step + row_b, R{});
+                dst[j] = C{a.x, b.x};
             }
-    } else if constexpr (MODE == DSC_MODE_C2R_PACKED) {             // sample pair (2k, 2k + 1) = (re, im) of z[k]: two rows of the output axis
-        const int voff = live ? (2 * t * inner + col) * RB : kOut;
-        const int row_b = inner * RB;
+        } else if constexpr (MODE == DSC_MODE_R2C_CAST) {           // dsc_fft / dsc_ifft of a real tensor: widened while loading
+            const int voff = live ? (t * inner + col) * RB : kOut;
+            const int step = T * inner * RB;
 #pragma unroll
-        for (int i = 0; i < CPT; ++i)
+            for (int j = 0; j < N; ++j) dst[j] = buf_load_real<kStream>(rin, voff, (J0 + j) * step, R{});
+        } else if constexpr (MODE == DSC_MODE_C2R_PACKED) {
+            const int step = T * inner * CB;
+            const int voff_k = live ? (t * inner + col) * CB : kOut;
+            const int voff_m = live ? (((L - 15 * T) - t) * inner + col) * CB : kOut;
 #pragma unroll
-            for (int p = 0; p < B; ++p) {
-                const C r = v[i * B + p];
-                const int soff = 2 * (T * i + COLS * brev(p, LOGB)) * row_b;
+            for (int j = 0; j < N; ++j) {
+                const int jj = J0 + j;
+                dst[j] = jj < 16 ? buf_load<kStream>(rin, voff_k, jj * step, R{}) : buf_load<kStream>(rin, voff_m, (31 - jj) * step, R{});
+            }
+        } else {
+            const int voff = live ? (t * inner + col) * CB : kOut;
+            const int step = T * inner * CB;
+#pragma unroll
+            for (int j = 0; j < N; ++j) dst[j] = buf_load<kStream>(rin, voff, (J0 + j) * step, R{});
+        }
+    };
+    auto request_mid = [&](int tile) {                              // C2R: bin L/2, which pairs with itself (thread 0 of a column)
+        C y = C{(R) 0, (R) 0};
+        const int tid = tid_now(), c = tid % CW, t = tid / CW;
+        if (MODE == DSC_MODE_C2R_PACKED && t == 0) {
+            const int col = col_of(tile, c);
+            y = buf_load<kStream>(in_rsrc(tile), col < inner ? col * CB : kOut, (L / 2) * inner * CB, R{});
+        }
+        return y;
+    };
+    using i0 = std::integral_constant<int, 0>;
+    using i16 = std::integral_constant<int, 16>;
+    using i32 = std::integral_constant<int, 32>;
+
+    C v[32];
+    request(v, i0{}, i32{}, (int) blockIdx.x);
+    C ymid = request_mid((int) blockIdx.x);
+    __syncthreads();                                                // twiddle table visible
+
+    int tile = blockIdx.x;
+    do {                                                            // one tile unless PIPE
+        const int next = PIPE ? tile + (int) gridDim.x : n_tiles;
+        const int slice = tile / tiles_per_slice;
+        const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
+            (void *) ((char *) out + (size_t) slice * out_axis * inner * OB), 0, out_axis * inner * OB, 0x00020000);
+
+        if constexpr (MODE == DSC_MODE_C2R_PACKED) {
+            const int tid = tid_now(), c = tid % CW, t = tid / CW;
+            R *stage = plane + c;                                   // stage[k * CW] = component of bin k of this column
+            // pair (k, L - k), k = T j + t, j < 16: a = Y[k] = v[j], b = Y[L - k] = v[16 + j];  s = a + conj b, d = a - conj b,
+            // wq = (i/2) conj(W_2L^k):  Z[k] = s/2 + wq d (kept),  Z[L - k] = conj(s/2 - wq d) (handed to its owner)   (dsc_fft.h:194-228)
+            const C wbase = tw_real[t];
+            if (t == 0) { v[0].y = (R) 0; v[16].y = (R) 0; }        // bins 0 and L: real parts only (dsc_fft.h:227-228)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const C w = cmul(wbase, C{(R) root64_re(j), (R) root64_im(j)});        // W_2L^{t + T j} = W_2L^t W_64^j
+                const R wqx = (R) 0.5 * w.y, wqy = (R) 0.5 * w.x;
+                const C a = v[j], b = v[16 + j];
+                const R sx = (R) 0.5 * (a.x + b.x), sy = (R) 0.5 * (a.y - b.y), dx = a.x - b.x, dy = a.y + b.y;
+                const R wdx = dx * wqx - dy * wqy, wdy = dx * wqy + dy * wqx;
+                v[j] = C{sx + wdx, sy + wdy};
+                v[16 + j] = C{sx - wdx, wdy - sy};
+            }
+            // Z[L - k] goes to staging index L - k; everybody then reads its own upper half k' = T j' + t, j' = 16 .. 31.  Thread 0
+            // pairs with itself (its Z[L - T j] are its own rows 32 - j) and supplies Z[L/2] = conj Y[L/2]; its write at index L is never read.
+            R *up = stage + ((L - 15 * T) - t) * CW;                // index L - T j - t = (L - 15 T - t) + T (15 - j)
+            const R *dn = stage + (16 * T + t) * CW;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) up[T * (15 - j) * CW] = v[16 + j].x;
+            if (t == 0) stage[(L / 2) * CW] = ymid.x;
+            lds_barrier();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[16 + j].x = dn[T * j * CW];
+            lds_barrier();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) up[T * (15 - j) * CW] = v[16 + j].y;
+            if (t == 0) stage[(L / 2) * CW] = -ymid.y;
+            lds_barrier();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[16 + j].y = dn[T * j * CW];
+        }
+        lds_barrier();              // staging reads (this tile's pre-pass, the previous tile's post-pass) done before the plane is reused
+
+        {
+            const int tid = tid_now();
+            cols_passes<R, B, TWO, CW, INV>(v, plane, wtab, tw_full, tid / CW, tid % CW);
+        }
+        const int tid = tid_now(), c = tid % CW, t = tid / CW;
+        const int col = col_of(tile, c);
+        const bool live = col < inner;
+        R *stage = plane + c;                                       // stage[k * CW] = component of bin k of this column
+
+        if constexpr (MODE == DSC_MODE_C2C || MODE == DSC_MODE_R2C_CAST) {
+            const int voff = live ? (t * inner + col) * CB : kOut;
+            const int step = inner * CB;
+            auto put = [&](int q) {                                 // q = i B + p
+                const C r = v[q];
+                buf_store<kStream>(C{r.x * scale, r.y * scale}, rout, voff, (T * (q / B) + COLS * brev(q % B, LOGB)) * step);
+            };
+            if constexpr (PIPE) {
+                // (the scheduling fences keep hipcc from hoisting all 32 loads in front of the stores: v[] would still be live)
+                __builtin_amdgcn_sched_barrier(0);
+                C nx[16];
+                request(nx, i0{}, i16{}, next);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) put(q);
+                __builtin_amdgcn_sched_barrier(0);
+                C ny[16];
+                request(ny, i16{}, i16{}, next);                    // into the registers the first sixteen stores have read
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 16; q < 32; ++q) put(q);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { v[j] = nx[j]; v[16 + j] = ny[j]; }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 32; ++q) put(q);
+            }
+        } else if constexpr (MODE == DSC_MODE_C2R_PACKED) {         // sample pair (2k, 2k + 1) = (re, im) of z[k]: two rows of the output axis
+            const int voff = live ? (2 * t * inner + col) * RB : kOut;
+            const int row_b = inner * RB;
+            auto put = [&](int q) {
+                const C r = v[q];
+                const int soff = 2 * (T * (q / B) + COLS * brev(q % B, LOGB)) * row_b;
                 store_real(r.x * scale, rout, voff, soff);
                 store_real(r.y * scale, rout, voff, soff + row_b);
+            };
+            if constexpr (PIPE) {
+                __builtin_amdgcn_sched_barrier(0);
+                C nx[16];
+                request(nx, i0{}, i16{}, next);
+                ymid = request_mid(next);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) put(q);
+                __builtin_amdgcn_sched_barrier(0);
+                C ny[16];
+                request(ny, i16{}, i16{}, next);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 16; q < 32; ++q) put(q);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { v[j] = nx[j]; v[16 + j] = ny[j]; }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 32; ++q) put(q);
             }
-    } else {
-        // packed-real post-pass (dsc_fft.h:199-225), one thread per PAIR (k, L-k), k = t + T i < L/2, plus k = L/2 (thread 0)
-        const C wbase = tw_real[t];
-        R ax[16], bx[16], amx = (R) 0;
-        R *up = stage + t * CW;
-        const R *dn = stage + ((L - 15 * T) - t) * CW;
+        } else {
+            // packed-real post-pass (dsc_fft.h:199-225), one thread per PAIR (k, L-k), k = t + T i < L/2, plus k = L/2 (thread 0)
+            const C wbase = tw_real[t];
+            R ax[16], bx[16], amx = (R) 0;
+            R *up = stage + t * CW;
+            const R *dn = stage + ((L - 15 * T) - t) * CW;
 #pragma unroll
-        for (int i = 0; i < CPT; ++i)
+            for (int i = 0; i < CPT; ++i)
 #pragma unroll
-            for (int p = 0; p < B; ++p) up[(T * i + COLS * brev(p, LOGB)) * CW] = v[i * B + p].x;
-        if (t == 0) stage[L * CW] = v[0].x;                                   // Z[L] := Z[0]
-        lds_barrier();
+                for (int p = 0; p < B; ++p) up[(T * i + COLS * brev(p, LOGB)) * CW] = v[i * B + p].x;
+            if (t == 0) stage[L * CW] = v[0].x;                                   // Z[L] := Z[0]
+            lds_barrier();
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { ax[i] = up[T * i * CW]; bx[i] = dn[T * (15 - i) * CW]; }
-        if (t == 0) amx = stage[(L / 2) * CW];
-        lds_barrier();
+            for (int i = 0; i < 16; ++i) { ax[i] = up[T * i * CW]; bx[i] = dn[T * (15 - i) * CW]; }
+            if (t == 0) amx = stage[(L / 2) * CW];
+            lds_barrier();
 #pragma unroll
-        for (int i = 0; i < CPT; ++i)
+            for (int i = 0; i < CPT; ++i)
 #pragma unroll
-            for (int p = 0; p < B; ++p) up[(T * i + COLS * brev(p, LOGB)) * CW] = v[i * B + p].y;
-        if (t == 0) stage[L * CW] = v[0].y;
-        lds_barrier();
-        const int step = inner * CB;
-        const int voff_k = live ? (t * inner + col) * CB : kOut;
-        const int voff_m = live ? (((L - 15 * T) - t) * inner + col) * CB : kOut;
+                for (int p = 0; p < B; ++p) up[(T * i + COLS * brev(p, LOGB)) * CW] = v[i * B + p].y;
+            if (t == 0) stage[L * CW] = v[0].y;
+            if constexpr (PIPE) {                                   // v is in the staging plane: its registers take the next tile
+                __builtin_amdgcn_sched_barrier(0);
+                request(v, i0{}, i32{}, next);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            lds_barrier();
+            const int step = inner * CB;
+            const int voff_k = live ? (t * inner + col) * CB : kOut;
+            const int voff_m = live ? (((L - 15 * T) - t) * inner + col) * CB : kOut;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const R ay = up[T * i * CW], by = dn[T * (15 - i) * CW];
-            const C w = cmul(wbase, C{(R) root64_re(i), (R) root64_im(i)});        // W_2L^{t + T i} = W_2L^t W_64^i
-            const R wqx = (R) 0.5 * w.y, wqy = (R) -0.5 * w.x;
-            const R sx = ax[i] + bx[i], sy = ay - by, dx = ax[i] - bx[i], dy = ay + by;
-            const R wdx = dx * wqx - dy * wqy, wdy = dx * wqy + dy * wqx;
-            C xk = C{(R) 0.5 * sx + wdx, (R) 0.5 * sy + wdy};
-            C xm = C{(R) 0.5 * sx - wdx, wdy - (R) 0.5 * sy};
-            if (i == 0 && t == 0) { xk.y = (R) 0; xm.y = (R) 0; }           // dsc_fft.h:221-225 stores exact zeros
-            buf_store<kStream>(C{xk.x * scale, xk.y * scale}, rout, voff_k, T * i * step);
-            buf_store<kStream>(C{xm.x * scale, xm.y * scale}, rout, voff_m, T * (15 - i) * step);
+            for (int i = 0; i < 16; ++i) {
+                const R ay = up[T * i * CW], by = dn[T * (15 - i) * CW];
+                const C w = cmul(wbase, C{(R) root64_re(i), (R) root64_im(i)});        // W_2L^{t + T i} = W_2L^t W_64^i
+                const R wqx = (R) 0.5 * w.y, wqy = (R) -0.5 * w.x;
+                const R sx = ax[i] + bx[i], sy = ay - by, dx = ax[i] - bx[i], dy = ay + by;
+                const R wdx = dx * wqx - dy * wqy, wdy = dx * wqy + dy * wqx;
+                C xk = C{(R) 0.5 * sx + wdx, (R) 0.5 * sy + wdy};
+                C xm = C{(R) 0.5 * sx - wdx, wdy - (R) 0.5 * sy};
+                if (i == 0 && t == 0) { xk.y = (R) 0; xm.y = (R) 0; }           // dsc_fft.h:221-225 stores exact zeros
+                buf_store<kStream>(C{xk.x * scale, xk.y * scale}, rout, voff_k, T * i * step);
+                buf_store<kStream>(C{xm.x * scale, xm.y * scale}, rout, voff_m, T * (15 - i) * step);
+            }
+            if (t == 0) {                                                     // k = L/2: a = b, W_2L^{L/2} = -i
+                const R ay = stage[(L / 2) * CW];
+                buf_store<kStream>(C{amx * scale, -ay * scale}, rout, voff_k, (L / 2) * step);
+            }
         }
-        if (t == 0) {                                                     // k = L/2: a = b, W_2L^{L/2} = -i
-            const R ay = stage[(L / 2) * CW];
-            buf_store<kStream>(C{amx * scale, -ay * scale}, rout, voff_k, (L / 2) * step);
-        }
-    }
+    } while (PIPE && (tile += (int) gridDim.x) < n_tiles);
 }
 
 #ifndef DSC_COLS_CW_1024
@@ -309,7 +399,17 @@ void launch_cols_one(const void *in, void *out, long long slices, int inner, int
         DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) fft_cols_kernel<R, B, TWO, CW, MODE, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     }
     const int tiles = (inner + CW - 1) / CW;
-    DSC_LAUNCH((fft_cols_kernel<R, B, TWO, CW, MODE, INV>), dim3((unsigned) (slices * tiles)), dim3(cfg::NT), lds, stream, in, out, inner, tiles,
+    const long long n_tiles = slices * tiles;
+    long long grid = n_tiles;
+    if (!TWO) {                                             // persistent: one workgroup per CU walks the tiles
+        static int cus[64];
+        int dev = 0;
+        DSC_KERNEL_CHECK(hipGetDevice(&dev));
+        dev &= 63;
+        if (cus[dev] == 0) DSC_KERNEL_CHECK(hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev));
+        if (grid > cus[dev]) grid = cus[dev];
+    }
+    DSC_LAUNCH((fft_cols_kernel<R, B, TWO, CW, MODE, INV>), dim3((unsigned) grid), dim3(cfg::NT), lds, stream, in, out, inner, tiles, (int) n_tiles,
                in_axis, in_len, out_axis, (const cpx<R> *) tw_full, (const cpx<R> *) tw_real, (R) scale);
 }
 

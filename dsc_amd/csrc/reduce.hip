@@ -294,14 +294,10 @@ void launch_op(const void *x, void *out, long long outer, int axis_n, long long 
             R *pi = pr + n_seg * n_out_all;
             int *pidx = (int *) (pi + n_seg * n_out_all);
             const unsigned bx = (unsigned) ((n_out_all + 255) / 256);
-            if (packs) {
-                const unsigned bxv = (unsigned) ((n_out_all / VP + 255) / 256);
-                DSC_LAUNCH((reduce_seg_kernel<R, CPLX, OP, VP>), dim3(bxv, (unsigned) n_seg), dim3(256), 0, s, x, pr, pi, pidx, outer,
-                                   axis_n, inner, seg_len);
-            } else {
-                DSC_LAUNCH((reduce_seg_kernel<R, CPLX, OP, 1>), dim3(bx, (unsigned) n_seg), dim3(256), 0, s, x, pr, pi, pidx, outer,
-                                   axis_n, inner, seg_len);
-            }
+            // (one output per thread: the pack form needs 131072 packs = 262144+ outputs, which this path — fewer than 262144
+            // outputs — never has; only the V = 1 form of the kernel is instantiated)
+            DSC_LAUNCH((reduce_seg_kernel<R, CPLX, OP, 1>), dim3(bx, (unsigned) n_seg), dim3(256), 0, s, x, pr, pi, pidx, outer,
+                               axis_n, inner, seg_len);
             DSC_LAUNCH((reduce_combine_kernel<R, CPLX, OP>), dim3(bx), dim3(256), 0, s, pr, pi, pidx, out, n_out_all,
                                (int) n_seg, axis_n);
             return;
