@@ -42,6 +42,7 @@ template<typename R, int B, bool TWO, int CW> struct cols_cfg {
     static constexpr int TABLE = TWO ? L : 1024;       // W_L^m (two-pass) or W_1024^m
     static constexpr int TABLE_STRIDE = TWO ? 1 : B;
     static constexpr int WAVES_PER_EU = NT >= 1024 ? 4 : sizeof(R) == 8 ? 2 : NT >= 512 ? 4 : 2;
+    static constexpr bool PIPE = false;                // persistent, software-pipelined tile loop (three-pass forms): measured, off
 };
 template<typename R, int B, bool TWO, int CW>
 constexpr size_t cols_lds_bytes() { return ((size_t) cols_cfg<R, B, TWO, CW>::PLANE + 2 * cols_cfg<R, B, TWO, CW>::TABLE) * sizeof(R); }
@@ -147,7 +148,13 @@ __global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO,
     constexpr int IB = (MODE == DSC_MODE_R2C_PACKED || MODE == DSC_MODE_R2C_CAST) ? RB : CB;       // bytes per input element
     constexpr int OB = MODE == DSC_MODE_C2R_PACKED ? RB : CB;       // bytes per output element
     constexpr int kOut = 0x7f000000;                                // an offset past every descriptor range: reads 0, stores dropped
-    constexpr bool PIPE = !TWO;                                     // persistent, next tile requested ahead of the stores
+    // PIPE: persistent + next tile requested ahead of the stores.  Built and measured in round 3 (profiles/r03_cols_axis0.md): it does
+    // not pay — 2048-point c32 lines 0.648 ms against 0.584 ms, 4096-point 1.27 against 1.13 — because these tiles are not limited by
+    // the overlap of their phases but by the size of their pieces (16 / 8 columns = 128 / 64 B per row of the tensor); kept, off.
+    constexpr bool PIPE = cfg::PIPE && !TWO;
+    // the inverse pre-pass with every pair handled once (see above): the f32 forms lose their spills with it (14 - 25 -> 0 - 4),
+    // the f64 forms get more (6 - 35 -> 19 - 54: hipcc starts all sixteen pairs at once), so they keep the two-exchange form
+    constexpr bool PAIR_ONCE = sizeof(R) == 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     R *plane = (R *) lds_raw;
     C *wtab = (C *) (plane + cfg::PLANE);
@@ -155,7 +162,7 @@ __global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO,
     for (int i = threadIdx.x; i < cfg::TABLE; i += NT) wtab[i] = tw_full[(long long) i * cfg::TABLE_STRIDE];
     // Everything derived from the thread id is loop invariant: hipcc hoists it out of the persistent loop (dozens of addresses) and
     // then spills.  Each phase therefore rebuilds (t, c) from an opaque copy of the id, so that nothing outlives its phase.
-    auto tid_now = [&]() { int x = (int) threadIdx.x; asm volatile("" : "+v"(x)); return x; };
+    auto tid_now = [&]() { int x = (int) threadIdx.x; if constexpr (PIPE) asm volatile("" : "+v"(x)); return x; };
 
     // descriptor of a tile's input slice (wave uniform) and a lane's column in it; a tile past the end reads zeros
     auto in_rsrc = [&](int tile) {
@@ -184,7 +191,7 @@ __global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO,
             const int step = T * inner * RB;
 #pragma unroll
             for (int j = 0; j < N; ++j) dst[j] = buf_load_real<kStream>(rin, voff, (J0 + j) * step, R{});
-        } else if constexpr (MODE == DSC_MODE_C2R_PACKED) {
+        } else if constexpr (MODE == DSC_MODE_C2R_PACKED && PAIR_ONCE) {
             const int step = T * inner * CB;
             const int voff_k = live ? (t * inner + col) * CB : kOut;
             const int voff_m = live ? (((L - 15 * T) - t) * inner + col) * CB : kOut;
@@ -200,12 +207,12 @@ __global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO,
             for (int j = 0; j < N; ++j) dst[j] = buf_load<kStream>(rin, voff, (J0 + j) * step, R{});
         }
     };
-    auto request_mid = [&](int tile) {                              // C2R: bin L/2, which pairs with itself (thread 0 of a column)
+    auto request_mid = [&](int tile) {                              // C2R, thread 0 of a column: bin L/2, which pairs with itself (two-exchange form: bin L)
         C y = C{(R) 0, (R) 0};
         const int tid = tid_now(), c = tid % CW, t = tid / CW;
         if (MODE == DSC_MODE_C2R_PACKED && t == 0) {
             const int col = col_of(tile, c);
-            y = buf_load<kStream>(in_rsrc(tile), col < inner ? col * CB : kOut, (L / 2) * inner * CB, R{});
+            y = buf_load<kStream>(in_rsrc(tile), col < inner ? col * CB : kOut, (PAIR_ONCE ? L / 2 : L) * inner * CB, R{});
         }
         return y;
     };
@@ -213,9 +220,17 @@ __global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO,
     using i16 = std::integral_constant<int, 16>;
     using i32 = std::integral_constant<int, 32>;
 
+    // C2R: the pre-pass twiddle of this thread, requested FIRST — arriving after the data it lets hipcc start all sixteen pairs
+    // (their sums and differences) and hold them until it is there: 40 - 90 spilled registers
+    C wpre = C{(R) 0, (R) 0};
+    if constexpr (MODE == DSC_MODE_C2R_PACKED && sizeof(R) == 4) {
+        wpre = tw_real[tid_now() / CW];
+        asm volatile("" : "+v"(wpre.x), "+v"(wpre.y));
+    }
     C v[32];
     request(v, i0{}, i32{}, (int) blockIdx.x);
-    C ymid = request_mid((int) blockIdx.x);
+    C ymid = C{(R) 0, (R) 0};
+    if constexpr (PAIR_ONCE) ymid = request_mid((int) blockIdx.x);
     __syncthreads();                                                // twiddle table visible
 
     int tile = blockIdx.x;
@@ -225,12 +240,49 @@ __global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO,
         const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
             (void *) ((char *) out + (size_t) slice * out_axis * inner * OB), 0, out_axis * inner * OB, 0x00020000);
 
-        if constexpr (MODE == DSC_MODE_C2R_PACKED) {
+        if constexpr (MODE == DSC_MODE_C2R_PACKED && !PAIR_ONCE) {
+            // Z[k] = (a + conj b)/2 + wq (a - conj b), a = Y[k], b = Y[L-k], wq = (i/2) conj(W_2L^k), k = T j1 + t (dsc_fft.h:194-228):
+            // every thread for its own 32 bins, b through the staging plane one component at a time
+            const int tid = tid_now(), c = tid % CW, t = tid / CW;
+            R *stage = plane + c;
+            const C wbase = tw_real[t];
+            C yl = request_mid(tile);                               // bin L (thread 0), requested here as the round-2 form did
+            if (t == 0) { v[0].y = (R) 0; yl.y = (R) 0; }           // bins 0 and L: real parts only (dsc_fft.h:227-228)
+            R dx[32];
+            R *up = stage + t * CW;
+            const R *dn = stage + ((L - 31 * T) - t) * CW;
+#pragma unroll
+            for (int j1 = 0; j1 < 32; ++j1) up[T * j1 * CW] = v[j1].x;
+            if (t == 0) stage[L * CW] = yl.x;
+            lds_barrier();
+#pragma unroll
+            for (int j1 = 0; j1 < 32; ++j1) {
+                const R bx = dn[T * (31 - j1) * CW];
+                dx[j1] = v[j1].x - bx;
+                v[j1].x = v[j1].x + bx;
+            }
+            lds_barrier();
+#pragma unroll
+            for (int j1 = 0; j1 < 32; ++j1) up[T * j1 * CW] = v[j1].y;
+            if (t == 0) stage[L * CW] = yl.y;
+            lds_barrier();
+#pragma unroll
+            for (int j1 = 0; j1 < 32; ++j1) {
+                const R by = dn[T * (31 - j1) * CW];
+                const C w = cmul(wbase, C{(R) root64_re(j1), (R) root64_im(j1)});      // W_2L^{t + T j1} = W_2L^t W_64^{j1}
+                const R wqx = (R) 0.5 * w.y, wqy = (R) 0.5 * w.x;
+                const R sy = v[j1].y - by, dy = v[j1].y + by;
+                const R zx = (R) 0.5 * v[j1].x + (dx[j1] * wqx - dy * wqy);
+                const R zy = (R) 0.5 * sy + (dx[j1] * wqy + dy * wqx);
+                v[j1] = C{zx, zy};
+            }
+        }
+        if constexpr (MODE == DSC_MODE_C2R_PACKED && PAIR_ONCE) {
             const int tid = tid_now(), c = tid % CW, t = tid / CW;
             R *stage = plane + c;                                   // stage[k * CW] = component of bin k of this column
             // pair (k, L - k), k = T j + t, j < 16: a = Y[k] = v[j], b = Y[L - k] = v[16 + j];  s = a + conj b, d = a - conj b,
             // wq = (i/2) conj(W_2L^k):  Z[k] = s/2 + wq d (kept),  Z[L - k] = conj(s/2 - wq d) (handed to its owner)   (dsc_fft.h:194-228)
-            const C wbase = tw_real[t];
+            const C wbase = wpre;
             if (t == 0) { v[0].y = (R) 0; v[16].y = (R) 0; }        // bins 0 and L: real parts only (dsc_fft.h:227-228)
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -401,7 +453,7 @@ void launch_cols_one(const void *in, void *out, long long slices, int inner, int
     const int tiles = (inner + CW - 1) / CW;
     const long long n_tiles = slices * tiles;
     long long grid = n_tiles;
-    if (!TWO) {                                             // persistent: one workgroup per CU walks the tiles
+    if (cfg::PIPE && !TWO) {                                // persistent: one workgroup per CU walks the tiles
         static int cus[64];
         int dev = 0;
         DSC_KERNEL_CHECK(hipGetDevice(&dev));

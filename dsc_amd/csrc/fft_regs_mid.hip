@@ -265,10 +265,16 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
     for (int i = tid; i < cfg::TABLE; i += NT) wtab[i] = tw_full[(long long) i * cfg::TABLE_STRIDE];    // W_1024^m = W_L^{B m}
 
     C v[32];
+    // The pair-once inverse pre-pass below where it removes spills: the f32 lines of 16384 points (11 spilled registers -> 4; irfft
+    // N = 32768 0.885 -> 0.799 ms, 60.7 -> 67.2 % of the roofline).  The shorter f32 lines had nothing to lose (1 - 2 % slower with it,
+    // tools/bench_mid.py on one box) and the f64 forms spill MORE with it (0 - 31 -> 31 - 51: hipcc starts all sixteen pairs at once);
+    // both keep the two-exchange form.
+    constexpr bool PAIR_ONCE = sizeof(R) == 4 && !TWO && B == 16;
+    if constexpr (MODE != DSC_MODE_C2R_PACKED || !PAIR_ONCE) {
 #pragma unroll
-    for (int j1 = 0; j1 < 32; ++j1) v[j1] = load_elem(T * j1);                               // z[T j1 + t]
-
-    if constexpr (MODE == DSC_MODE_C2R_PACKED) {
+        for (int j1 = 0; j1 < 32; ++j1) v[j1] = load_elem(T * j1);                           // z[T j1 + t]
+    }
+    if constexpr (MODE == DSC_MODE_C2R_PACKED && !PAIR_ONCE) {
         // Z[k] = (a + conj b)/2 + wq (a - conj b), a = Y[k], b = Y[L-k], wq = (i/2) conj(W_2L^k), for the
         // thread's own k = T j1 + t; b comes through the staging plane, one component at a time.
         const C wbase = tw_real[t];
@@ -302,6 +308,50 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
             const R zy = (R) 0.5 * sy + (dx[j1] * wqy + dy * wqx);
             v[j1] = C{zx, zy};
         }
+    }
+    if constexpr (MODE == DSC_MODE_C2R_PACKED && PAIR_ONCE) {
+        // Inverse packed-real pre-pass (dsc_fft.h:194-228), every pair (k, L - k) ONCE (round 3): the thread loads its lower sixteen bins
+        // k = T j + t AND their partners Y[L - k] (descending addresses across the lanes: the same coalesced pieces as its own upper half),
+        // computes  s = a + conj b, d = a - conj b, wq = (i/2) conj(W_2L^k):  Z[k] = s/2 + wq d  (kept),  Z[L - k] = conj(s/2 - wq d)
+        // and hands Z[L - k] to its owner through the staging plane — half the arithmetic of "everybody computes its own 32 bins", one
+        // exchange instead of two and no second 32-value array (that form spilled 2 - 38 registers).
+        const C wbase = tw_real[t];                                 // requested first: the pairs wait for it
+        constexpr int kOut = 0x7f000000;
+        const int vin_m = g * pitch_b + ((L - 15 * T) - t) * CB;    // element L - T j - t = (L - 15 T - t) + T (15 - j)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            v[j] = load_elem(T * j);
+            v[16 + j] = buf_load<LOADP>(rin, (!PAD || ((L - 15 * T) - t + T * (15 - j)) * CB < in_len_b) ? vin_m : kOut, T * (15 - j) * CB, R{});
+        }
+        C ymid = C{(R) 0, (R) 0};
+        if (t == 0) { ymid = load_elem(L / 2); v[0].y = (R) 0; v[16].y = (R) 0; }   // bin L/2 pairs with itself; bins 0 and L: real parts only (dsc_fft.h:227-228)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const C w = cmul(wbase, C{(R) root64_re(j), (R) root64_im(j)});        // W_2L^{t + T j} = W_2L^t W_64^j
+            const R wqx = (R) 0.5 * w.y, wqy = (R) 0.5 * w.x;
+            const C a = v[j], b = v[16 + j];
+            const R sx = (R) 0.5 * (a.x + b.x), sy = (R) 0.5 * (a.y - b.y), dx = a.x - b.x, dy = a.y + b.y;
+            const R wdx = dx * wqx - dy * wqy, wdy = dx * wqy + dy * wqx;
+            v[j] = C{sx + wdx, sy + wdy};
+            v[16 + j] = C{sx - wdx, wdy - sy};
+        }
+        // Z[L - k] goes to staging index L - k; everybody then reads its own upper half T j' + t, j' = 16 .. 31.  Thread 0 pairs with itself
+        // (its Z[L - T j] are its own rows 32 - j) and supplies Z[L/2] = conj Y[L/2]; its write at index L is never read.
+        R *up = stage + (L - 15 * T) - t;           // up[T (15 - j)] = stage[L - k]
+        const R *dn = stage + 16 * T + t;           // dn[T j]        = stage[T (16 + j) + t]
+#pragma unroll
+        for (int j = 0; j < 16; ++j) up[T * (15 - j)] = v[16 + j].x;
+        if (t == 0) stage[L / 2] = ymid.x;
+        lds_barrier();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[16 + j].x = dn[T * j];
+        lds_barrier();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) up[T * (15 - j)] = v[16 + j].y;
+        if (t == 0) stage[L / 2] = -ymid.y;
+        lds_barrier();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[16 + j].y = dn[T * j];
     }
     __syncthreads();                // twiddle table visible; staging reads done before the plane is reused
 

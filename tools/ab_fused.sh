@@ -17,7 +17,7 @@ for c in $PMC; do
   for L in "$@"; do
     n=$(basename $L .so)
     for ctr in FETCH_SIZE WRITE_SIZE; do
-      DSC_MI355X_LIB=$PWD/$L timeout -k 10 200 rocprofv3 --pmc $ctr --output-format csv -d $OUT/pmc_${n}_${c}_$ctr -- python3 tools/run_op.py $c --iters 3 > /dev/null 2> $OUT/pmc_${n}_${c}_$ctr.err || tail -2 $OUT/pmc_${n}_${c}_$ctr.err
+      DSC_MI355X_LIB=$PWD/$L timeout -k 10 200 rocprofv3 --pmc $ctr --output-format csv -d $OUT/pmc_${n}_${c}_$ctr -- python3 tools/run_op.py $c --iters 3 --ramp-ms 0 > /dev/null 2> $OUT/pmc_${n}_${c}_$ctr.err || tail -2 $OUT/pmc_${n}_${c}_$ctr.err
     done
   done
 done

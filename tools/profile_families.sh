@@ -30,7 +30,7 @@ for c in $PMC_CASES; do
   i=0
   for set in "${PASSES[@]}"; do
     i=$((i+1))
-    timeout -k 10 120 rocprofv3 --pmc $set --output-format csv -d $D/pmc$i -- python3 tools/run_op.py $c --iters 3 > /dev/null 2> $D/pmc$i.err || { echo "$c pass $i ($set) failed"; tail -2 $D/pmc$i.err; }
+    timeout -k 10 120 rocprofv3 --pmc $set --output-format csv -d $D/pmc$i -- python3 tools/run_op.py $c --iters 3 --ramp-ms 0 > /dev/null 2> $D/pmc$i.err || { echo "$c pass $i ($set) failed"; tail -2 $D/pmc$i.err; }
     echo "$c pmc pass $i done"
 
   done

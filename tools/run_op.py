@@ -192,6 +192,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('case', nargs='?')
     ap.add_argument('--iters', type=int, default=30)
+    ap.add_argument('--ramp-ms', type=float, default=100.0, help='untimed launches for this long before the warm-up, as bench.py does (0 disables)')
     ap.add_argument('--list', action='store_true')
     args = ap.parse_args()
     if args.list:
@@ -206,6 +207,13 @@ def main():
     dsc.init(20 << 30, 6 << 30)
     ctx = _get_ctx()
     f, nbytes, keep = CASES[args.case](dsc, B, ctx, np)
+    # the same untimed clock ramp as bench.py (the uploads above left the GPU idle): --ramp-ms of launches, then the warm-up
+    import time
+    t_end = time.perf_counter() + args.ramp_ms / 1e3
+    while time.perf_counter() < t_end:
+        for _ in range(5):
+            f()
+        dsc.synchronize()
     for _ in range(max(5, args.iters // 3)):
         f()
     dsc.synchronize()
