@@ -231,8 +231,8 @@ __global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO,
     request(v, i0{}, i32{}, (int) blockIdx.x);
     C ymid = C{(R) 0, (R) 0};
     if constexpr (PAIR_ONCE) ymid = request_mid((int) blockIdx.x);
-    __syncthreads();                                                // twiddle table visible
-
+    if constexpr (PIPE) __syncthreads();                            // twiddle table visible (one-tile forms: at the barrier after the pre-pass,
+                                                                    // so that the loads are not all waited for at once)
     int tile = blockIdx.x;
     do {                                                            // one tile unless PIPE
         const int next = PIPE ? tile + (int) gridDim.x : n_tiles;
@@ -312,7 +312,8 @@ __global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO,
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[16 + j].y = dn[T * j * CW];
         }
-        lds_barrier();              // staging reads (this tile's pre-pass, the previous tile's post-pass) done before the plane is reused
+        if constexpr (PIPE) lds_barrier();      // staging reads (this tile's pre-pass, the previous tile's post-pass) done before the plane is reused
+        else __syncthreads();                   // ... and the twiddle table visible
 
         {
             const int tid = tid_now();

@@ -193,8 +193,9 @@ def test_bench_two_ranks_on_one_gpu():
 
 
 def test_f64_262144_register_path(dsc):
-    """BASELINE config 5 (f64 N=262144): radix-8 pass + register-resident 16384-point passes +
-    post-pass.  Parity 1e-12 vs the oracle, round trip, path check, odd row counts (chunking)."""
+    """BASELINE config 5 (f64 N=262144) on the team kernel of fft_xcd_fused.hip (one cooperative launch: 512-point row tasks, 256-point
+    column tasks with the packed-real pass fused, the four-step intermediate in the XCD-local L2).  Parity 1e-12 vs the oracle, round
+    trip, path check, row counts that leave teams without a row."""
     from oracle import port
     rng = np.random.default_rng(55)
     for rows in (1, 3, 37):
