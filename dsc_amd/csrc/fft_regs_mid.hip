@@ -41,7 +41,8 @@ constexpr int two_pass_stride(int B) {
     return base;
 }
 
-template<typename R, int B, bool TWO> struct mid_cfg {
+// V: 0 = the transforms (fft_mid_kernel), 1 = the fused filter (fft_mid_filter_kernel) — the two want different group sizes at some lengths
+template<typename R, int B, bool TWO, int V = 0> struct mid_cfg {
     static constexpr bool DP = sizeof(R) == 8;
     static constexpr int T = TWO ? B : 32 * B;       // threads per line
     static constexpr int L = 32 * T;                 // complex length
@@ -72,8 +73,25 @@ template<typename R, int B, bool TWO> struct mid_cfg {
     // W_1024 table (W^(m + 512) = -W^m) is exactly 80 KiB: two independent groups per CU.
     static constexpr bool HALF = DP && !TWO && B == 8;
 #endif
+    // f32 group sizes, round 3 (tools/build_mid_variant.sh, one box, gpurun_out/r3e/mid_nt.txt): 2048-point lines (B = 2) in groups of
+    // 256 threads instead of 512 — four independent groups per CU instead of two: fused filter N = 4096 0.701 -> 0.646 ms (38.3 -> 41.6 %),
+    // irfft 71.2 -> 73.2 %, rfft 68.7 -> 69.8 % (128: no better); 8192-point lines (B = 8) in groups of 256 for the FILTER only (0.772 ->
+    // 0.695 ms, 34.8 -> 38.6 %; the transforms lose 2 % with it); 4096-point lines (B = 4) stay at 256 (128: filter 40.4 -> 37.9 %).
+#ifndef DSC_MID_NT_F32_B2
+#define DSC_MID_NT_F32_B2 256
+#endif
+#ifndef DSC_MID_NT_F32_B4
+#define DSC_MID_NT_F32_B4 256
+#endif
+#ifndef DSC_MID_NT_F32_B8
+#define DSC_MID_NT_F32_B8 512
+#endif
+#ifndef DSC_MID_NT_F32_B8_FILTER
+#define DSC_MID_NT_F32_B8_FILTER 256
+#endif
     static constexpr int NT = DP ? (TWO ? (B >= 32 ? 128 : 256) : HALF ? 256 : (B >= 8 ? 512 : 128))
-                                 : (TWO ? 256 : B >= 32 ? 1024 : (B >= 8 || (PACKED && !DP)) ? 512 : 256);
+                                 : (TWO ? 256 : B >= 32 ? 1024 : B == 16 ? 512 : B == 8 ? (V == 1 ? DSC_MID_NT_F32_B8_FILTER : DSC_MID_NT_F32_B8)
+                                                                                  : B == 4 ? DSC_MID_NT_F32_B4 : (PACKED ? DSC_MID_NT_F32_B2 : 256));
     static constexpr int G = NT / T;                 // lines per workgroup
     static constexpr int WAVES_PER_EU = DP ? 2 : (TWO ? 2 : (B >= 8 || PACKED) ? 4 : 2);   // f32: <= 128 VGPRs where two 512-thread groups share a CU
     static constexpr int P1 = 33;                    // exchange-1 row pitch (values): odd
@@ -93,8 +111,8 @@ template<typename R, int B, bool TWO> struct mid_cfg {
     static constexpr int TABLE_STRIDE = TWO ? 1 : B;
 };
 
-template<typename R, int B, bool TWO>
-constexpr size_t mid_lds_bytes() { return ((size_t) mid_cfg<R, B, TWO>::PLANE + 2 * mid_cfg<R, B, TWO>::TABLE) * sizeof(R); }
+template<typename R, int B, bool TWO, int V = 0>
+constexpr size_t mid_lds_bytes() { return ((size_t) mid_cfg<R, B, TWO, V>::PLANE + 2 * mid_cfg<R, B, TWO, V>::TABLE) * sizeof(R); }
 
 // W_1024^m from the LDS table; HALF: the table holds m < 512 and W^(m + 512) = -W^m
 template<typename R, bool HALF>
@@ -110,11 +128,11 @@ __device__ __forceinline__ cpx<R> table_entry(const cpx<R> *wtab, int m) {
 // The transform proper, shared by fft_mid_kernel and fft_mid_filter_kernel.  In: v[j1] = z[T j1 + t] of line g (natural
 // register order).  Out: v[i B + p] = bin k = (t + T i) + COLS brev(p) ("column layout").  Ends with an LDS barrier, i.e.
 // the plane is free on return (three-pass) or untouched since the last barrier.
-template<typename R, int B, bool TWO, bool INV>
+template<typename R, int B, bool TWO, bool INV, int V = 0>
 __device__ __forceinline__ void mid_passes(cpx<R> (&v)[32], R *plane, const cpx<R> *wtab, const cpx<R> *__restrict__ tw_full, int g, int t,
                                            int tid) {
     using C = cpx<R>;
-    using cfg = mid_cfg<R, B, TWO>;
+    using cfg = mid_cfg<R, B, TWO, V>;
     constexpr int T = cfg::T, P1 = cfg::P1, P2 = cfg::P2, CPT = cfg::CPT;
     const int hi = TWO ? 0 : t / B, lo = TWO ? t : t % B;
     C u[32];
@@ -416,11 +434,11 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
 // in the same thread, one staging round trip to bring the pairs back to the load layout, inverse passes: the spectrum
 // never leaves the CU.  s rows may be shorter than 2L (zero padded) or longer (cropped).
 template<typename R, int B, bool TWO>
-__global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVES_PER_EU)) void fft_mid_filter_kernel(
+__global__ __launch_bounds__((mid_cfg<R, B, TWO, 1>::NT), (mid_cfg<R, B, TWO, 1>::WAVES_PER_EU)) void fft_mid_filter_kernel(
     const R *__restrict__ s, const cpx<R> *__restrict__ H, cpx<R> *__restrict__ y, long long n_lines, const cpx<R> *__restrict__ tw_full,
     const cpx<R> *__restrict__ tw_real, int in_pitch_b, int in_len_b) {
     using C = cpx<R>;
-    using cfg = mid_cfg<R, B, TWO>;
+    using cfg = mid_cfg<R, B, TWO, 1>;
     constexpr int T = cfg::T, L = cfg::L, G = cfg::G, NT = cfg::NT, SP = cfg::SP, CPT = cfg::CPT, COLS = cfg::COLS;
     constexpr int LOGB = ilog2(B), CB = (int) sizeof(C);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -448,7 +466,7 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
         if (eoff + CB > in_len_b) v[j1].y = (R) 0;
     }
     __syncthreads();
-    mid_passes<R, B, TWO, false>(v, plane, wtab, tw_full, g, t, tid);     // v[i B + p] = Z[(t + T i) + COLS brev(p)]
+    mid_passes<R, B, TWO, false, 1>(v, plane, wtab, tw_full, g, t, tid);  // v[i B + p] = Z[(t + T i) + COLS brev(p)]
 
     // ---- the pair (k, L-k), k = t + T i, i < 16 (plus k = L/2 in thread 0): a = Z[k], b = Z[L-k] through the staging plane
     const C wbase = tw_real[t];
@@ -523,7 +541,7 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
     // registers for the inverse passes (common subexpressions) and the kernel needs 220 VGPRs
     const C *wtab_inv = wtab;
     asm volatile("" : "+v"(wtab_inv));
-    mid_passes<R, B, TWO, true>(v, plane, wtab_inv, tw_full, g, t, tid);
+    mid_passes<R, B, TWO, true, 1>(v, plane, wtab_inv, tw_full, g, t, tid);
     const R scale = (R) (1.0 / (double) L);                               // 2/(2n), dsc_fft.h:232
 #pragma unroll
     for (int i = 0; i < CPT; ++i)
@@ -537,8 +555,8 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
 template<typename R, int B, bool TWO>
 void launch_filter(const void *s, const void *H, void *y, long long n_lines, const void *tw_full, const void *tw_real, int in_pitch_b,
                    int in_len_b, hipStream_t stream) {
-    using cfg = mid_cfg<R, B, TWO>;
-    constexpr size_t lds = mid_lds_bytes<R, B, TWO>();
+    using cfg = mid_cfg<R, B, TWO, 1>;
+    constexpr size_t lds = mid_lds_bytes<R, B, TWO, 1>();
     static unsigned long long attr_devices = 0;
     if (dsc_first_use_on_device(attr_devices)) {
         DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) fft_mid_filter_kernel<R, B, TWO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));

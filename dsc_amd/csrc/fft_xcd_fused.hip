@@ -707,7 +707,10 @@ bool launch_one(const void *in, void *out, long long rows, void *scratch, unsign
     if (cap_env > 0 && cap_env < cap_i) cap_i = cap_env;
     const C *twf = (const C *) tw_full, *twr = (const C *) tw_real;
     R scale_r = (R) scale;
-    static const bool plain = getenv("DSC_FUSED_PLAIN_LAUNCH") != nullptr;
+    // Under rocprofv3 the ordinary launch is used as well: with cooperative dispatches in the trace, `rocprofv3 --kernel-trace --stats` on this
+    // image (ROCm 7.2.0) writes its files and then dies with SIGSEGV at process exit (gpurun_out/r03fam/fft_c32_65536/trace.err), which
+    // loses the per-kernel summaries under profiles/.  The two launches time within 0 - 4 % of each other.
+    static const bool plain = getenv("DSC_FUSED_PLAIN_LAUNCH") != nullptr || getenv("ROCPROF_OUTPUT_PATH") != nullptr || getenv("ROCPROFILER_LIBRARY_CTOR") != nullptr;
     if (plain) {
         DSC_LAUNCH((fused_l2_kernel<R, REAL, INV, L2, NT, CAST>), dim3((unsigned) grids[dev]), dim3(NT), 0, stream, ext_in, ext_out, bins_in, bins_out, rowsbuf, ctl,
                    host_error, rows_i, cap_i, twf, twr, scale_r, ext_pitch_b, ext_len_b, bins_pitch, bins_len);
