@@ -240,7 +240,23 @@ __global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO,
         const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
             (void *) ((char *) out + (size_t) slice * out_axis * inner * OB), 0, out_axis * inner * OB, 0x00020000);
 
-        if constexpr (MODE == DSC_MODE_C2R_PACKED && !PAIR_ONCE) {
+        if constexpr (MODE == DSC_MODE_C2R_PACKED && !PAIR_ONCE && T == 1) {
+            // 32-point lines, one thread per column: both partners of every pair live in this thread — no staging, no barrier.
+            // (k, L - k) = (j, 32 - j): a = v[j], b = v[32 - j]; W_2L^j = W_64^j, a compile-time constant.
+            const C yl = request_mid(tile);                         // bin L
+            { const R a = v[0].x, b = yl.x; v[0] = C{(R) 0.5 * (a + b), (R) 0.5 * (a - b)}; }       // bins 0 and L: real parts only (dsc_fft.h:227-232)
+#pragma unroll
+            for (int j = 1; j < 16; ++j) {
+                const R wqx = (R) (0.5 * root64_im(j)), wqy = (R) (0.5 * root64_re(j));             // wq = (i/2) conj(W_64^j)
+                const C a = v[j], b = v[32 - j];
+                const R sx = (R) 0.5 * (a.x + b.x), sy = (R) 0.5 * (a.y - b.y), dx = a.x - b.x, dy = a.y + b.y;
+                const R wdx = dx * wqx - dy * wqy, wdy = dx * wqy + dy * wqx;
+                v[j] = C{sx + wdx, sy + wdy};
+                v[32 - j] = C{sx - wdx, wdy - sy};
+            }
+            v[16].y = -v[16].y;                                     // Z[L/2] = conj Y[L/2]
+        }
+        if constexpr (MODE == DSC_MODE_C2R_PACKED && !PAIR_ONCE && T != 1) {
             // Z[k] = (a + conj b)/2 + wq (a - conj b), a = Y[k], b = Y[L-k], wq = (i/2) conj(W_2L^k), k = T j1 + t (dsc_fft.h:194-228):
             // every thread for its own 32 bins, b through the staging plane one component at a time
             const int tid = tid_now(), c = tid % CW, t = tid / CW;

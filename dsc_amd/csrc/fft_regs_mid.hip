@@ -76,7 +76,7 @@ template<typename R, int B, bool TWO, int V = 0> struct mid_cfg {
     // f32 group sizes, round 3 (tools/build_mid_variant.sh, one box, gpurun_out/r3e/mid_nt.txt): 2048-point lines (B = 2) in groups of
     // 256 threads instead of 512 — four independent groups per CU instead of two: fused filter N = 4096 0.701 -> 0.646 ms (38.3 -> 41.6 %),
     // irfft 71.2 -> 73.2 %, rfft 68.7 -> 69.8 % (128: no better); 8192-point lines (B = 8) in groups of 256 for the FILTER only (0.772 ->
-    // 0.695 ms, 34.8 -> 38.6 %; the transforms lose 2 % with it); 4096-point lines (B = 4) stay at 256 (128: filter 40.4 -> 37.9 %).
+    // 0.695 ms, 34.8 -> 38.6 %; the transforms lose 2 % with it); 4096-point lines (B = 4) stay at 256 (128: filter 40.4 -> 37.9 %; 512: everything 25 - 35 % slower).
 #ifndef DSC_MID_NT_F32_B2
 #define DSC_MID_NT_F32_B2 256
 #endif
@@ -86,11 +86,17 @@ template<typename R, int B, bool TWO, int V = 0> struct mid_cfg {
 #ifndef DSC_MID_NT_F32_B8
 #define DSC_MID_NT_F32_B8 512
 #endif
+#ifndef DSC_MID_NT_F32_TWO
+#define DSC_MID_NT_F32_TWO 128      // two-pass lines (512, 1024 points): groups of 128 (was 256): irfft N = 2048 66.8 -> 70.5 %, fft c32 L = 1024 68.7 -> 72.8 %, fused filter N = 1024 46.4 -> 50.4 %; 512: worse
+#endif
+#ifndef DSC_MID_NT_F64_TWO16
+#define DSC_MID_NT_F64_TWO16 256
+#endif
 #ifndef DSC_MID_NT_F32_B8_FILTER
 #define DSC_MID_NT_F32_B8_FILTER 256
 #endif
-    static constexpr int NT = DP ? (TWO ? (B >= 32 ? 128 : 256) : HALF ? 256 : (B >= 8 ? 512 : 128))
-                                 : (TWO ? 256 : B >= 32 ? 1024 : B == 16 ? 512 : B == 8 ? (V == 1 ? DSC_MID_NT_F32_B8_FILTER : DSC_MID_NT_F32_B8)
+    static constexpr int NT = DP ? (TWO ? (B >= 32 ? 128 : DSC_MID_NT_F64_TWO16) : HALF ? 256 : (B >= 8 ? 512 : 128))
+                                 : (TWO ? DSC_MID_NT_F32_TWO : B >= 32 ? 1024 : B == 16 ? 512 : B == 8 ? (V == 1 ? DSC_MID_NT_F32_B8_FILTER : DSC_MID_NT_F32_B8)
                                                                                   : B == 4 ? DSC_MID_NT_F32_B4 : (PACKED ? DSC_MID_NT_F32_B2 : 256));
     static constexpr int G = NT / T;                 // lines per workgroup
     static constexpr int WAVES_PER_EU = DP ? 2 : (TWO ? 2 : (B >= 8 || PACKED) ? 4 : 2);   // f32: <= 128 VGPRs where two 512-thread groups share a CU

@@ -50,6 +50,10 @@ constexpr int kPQ = 276, kPK = 17;        // row-task exchange: line pitch (valu
 #ifndef DSC_FUSED_BINS_STORE
 #define DSC_FUSED_BINS_STORE kCached
 #endif
+// workgroups per CU the f64 (256-thread) forms are built for and ask for: 2 = teams in pairs, 256 VGPRs; 3 caps the kernel at 168 VGPRs
+#ifndef DSC_FUSED_WG_PER_CU
+#define DSC_FUSED_WG_PER_CU 2
+#endif
 constexpr int kCoherent = 16;             // aux bits: sc1 (device scope: the load misses the L1)
 constexpr unsigned kSpinLimit = 1u << 22; // polls (each > 0.5 us) before a barrier gives up
 
@@ -152,7 +156,7 @@ __device__ __forceinline__ void four_step_twiddle16(cpx<R> (&v)[16], const cpx<R
 // CAST (complex transforms only): the input rows are REAL and widened on the way in (dsc_fft / dsc_ifft of a real tensor,
 // dsc.cpp:1984-1988).
 template<typename R, bool REAL, bool INV, int L2, int kNT, bool CAST = false>
-__global__ __launch_bounds__(kNT, (kNT == 512 ? 4 : 2)) void fused_l2_kernel(const char *__restrict__ ext, char *__restrict__ ext_out,
+__global__ __launch_bounds__(kNT, (kNT == 512 ? 4 : DSC_FUSED_WG_PER_CU)) void fused_l2_kernel(const char *__restrict__ ext, char *__restrict__ ext_out,
                                                                                const cpx<R> *__restrict__ bins_in, cpx<R> *__restrict__ bins_out,
                                                                                cpx<R> *scratch, fused_ctl *ctl, unsigned *host_error, int rows, int teams_cap,
                                                                                const cpx<R> *__restrict__ twL, const cpx<R> *__restrict__ tw_real, R scale,
@@ -663,7 +667,7 @@ __global__ __launch_bounds__(kNT, (kNT == 512 ? 4 : 2)) void fused_l2_kernel(con
 // (measured at L = 65536: rfft 1.48 -> 1.34 ms, irfft 1.59 -> 1.48 ms, fft 1.18 -> 1.15 ms; at 131072 the 256-thread form loses to
 // the two-kernel route).  f64: 256 threads (the same pieces in bytes).
 constexpr int threads_of(int L, bool single_precision) { (void) L; return single_precision ? 512 : 256; }
-constexpr int wg_per_cu(int L, bool single_precision) { (void) L; (void) single_precision; return 2; }     // teams work in pairs
+constexpr int wg_per_cu(int L, bool single_precision) { (void) L; (void) single_precision; return DSC_FUSED_WG_PER_CU; }     // teams work in pairs (3: measured)
 constexpr int team_size_of(int L, bool single_precision) { return (L / 256) / (threads_of(L, single_precision) / 16); }
 constexpr int teams_cap_of(int L, bool single_precision) {
     return wg_per_cu(L, single_precision) * 32 / team_size_of(L, single_precision) + 1;       // workgroups per XCD (32 CUs) / team size
@@ -684,11 +688,13 @@ bool launch_one(const void *in, void *out, long long rows, void *scratch, unsign
         int per_cu = 0, cus = 0;
         DSC_KERNEL_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *) fused_l2_kernel<R, REAL, INV, L2, NT, CAST>, NT, 0));
         DSC_KERNEL_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        const int per_cu_raw = per_cu;
         if (per_cu > wg_per_cu(L, sizeof(R) == 4)) per_cu = wg_per_cu(L, sizeof(R) == 4);
         int g = cus * per_cu;
         g -= g % (8 * TS);
         if (g > 8 * TS * (cap - 1)) g = 8 * TS * (cap - 1);
         grids[dev] = g >= 8 * TS ? g : -1;
+        if (getenv("DSC_FUSED_VERBOSE")) fprintf(stderr, "fused_l2: L2 = %d, %d threads: occupancy query %d per CU, asked %d, %d CUs -> grid %d (team size %d, teams cap %d)\n", L2, NT, per_cu_raw, wg_per_cu(L, sizeof(R) == 4), cus, grids[dev], TS, cap);
     }
     if (grids[dev] < 0) return false;
     fused_ctl *ctl = (fused_ctl *) scratch;
