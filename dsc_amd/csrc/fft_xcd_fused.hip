@@ -181,6 +181,11 @@ __global__ __launch_bounds__(kNT, (kNT == 512 ? 4 : DSC_FUSED_WG_PER_CU)) void f
     constexpr int W1 = TAB / 256, W2 = TAB / L2;
 
     // ---- teams
+    // (Round 3, measured and NOT adopted: forming the teams per CU — the first workgroup to arrive on a CU joins an even team, the second its odd
+    // partner, HW_REG_HW_ID[15:8] names the CU (tools/hwid_probe.hip) — removes the members that share a CU with a team mate and make the team
+    // barrier wait every row (profiles/r03_l2probe.md section 4), but then all 32 members store and read `A` in the same 3 us and the slot
+    // cycle stays at ~10 us: config 5 3.03 -> 3.05 ms, its inverse 3.08 -> 3.32, c64 ifft L = 131072 2.45 -> 2.84.  The arrival order spreads
+    // a team's members over the phases; it stays.)
     if (tid == 0) {
         const unsigned x = xcc_id() & 7u;                           // MI355X: 8 XCDs (the control block has 8 slots)
         const unsigned arr = l2_fetch_add(&ctl->xcc_count[x][0], 1u);
@@ -339,11 +344,16 @@ __global__ __launch_bounds__(kNT, (kNT == 512 ? 4 : DSC_FUSED_WG_PER_CU)) void f
 
 #ifdef DSC_FUSED_PROFILE
     unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pl = wall_clock64();
-#define PMARK(i) do { const unsigned long long n_ = wall_clock64(); pt[i] += n_ - pl; pl = n_; } while (0)
+    __shared__ unsigned long long pstamp[12][8];          // absolute stamps of rows 20 .. 31 of this workgroup (a timeline of both teams of a pair)
+    int pit = 0;
+#define PMARK(i) do { const unsigned long long n_ = wall_clock64(); pt[i] += n_ - pl; pl = n_; if (tid == 0 && pit >= 20 && pit < 32) pstamp[pit - 20][i] = n_; } while (0)
 #else
 #define PMARK(i) do { } while (0)
 #endif
     for (int it = 0; row < rows; ++it) {
+#ifdef DSC_FUSED_PROFILE
+        pit = it;
+#endif
         PMARK(0);
         // the previous row's last reads of the LDS plane (packed-real partners, or the second task's exchange) carry no barrier of
         // their own: no wave may start writing the plane for this row before every wave is done with it
@@ -654,6 +664,14 @@ __global__ __launch_bounds__(kNT, (kNT == 512 ? 4 : DSC_FUSED_WG_PER_CU)) void f
     }
     leave();
 #ifdef DSC_FUSED_PROFILE
+    if (tid == 0 && xcc == 0 && team == 0)                  // every member of one team, two rows: who is the barrier waiting for?
+        for (int r = 2; r < 4; ++r)
+            printf("fused_l2 members team %d rank %d row-iteration %d (10 ns ticks): top %llu | row task done %llu | slot free %llu | A stored, arrived %llu | team complete %llu | A read %llu | column task done %llu\n",
+                   team, rank, 20 + r, pstamp[r][0], pstamp[r][1], pstamp[r][2], pstamp[r][3], pstamp[r][4], pstamp[r][5], pstamp[r][6]);
+    if (tid == 0 && xcc == 0 && team < 2 && (rank == 0 || rank == kTS - 1))
+        for (int r = 0; r < 12; ++r)
+            printf("fused_l2 timeline team %d rank %d row-iteration %d (10 ns ticks): top %llu | row task done %llu | slot free %llu | A stored, arrived %llu | team complete %llu | A read %llu | column task done %llu\n",
+                   team, rank, 20 + r, pstamp[r][0], pstamp[r][1], pstamp[r][2], pstamp[r][3], pstamp[r][4], pstamp[r][5], pstamp[r][6]);
     if (tid == 0 && xcc == 0 && team == 0 && (rank == 0 || rank == 7))
         printf("fused_l2 profile rank %d (10 ns ticks, sums over the rows of this team): loop %llu | phase-1 compute %llu | wait B %llu | store A + arrive %llu | wait A %llu | read A + request %llu | phase 2 %llu\n",
                rank, pt[0], pt[1], pt[2], pt[3], pt[4], pt[5], pt[6]);
