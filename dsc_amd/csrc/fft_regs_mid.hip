@@ -592,7 +592,16 @@ void launch_filter_len(int L, const void *s, const void *H, void *y, long long n
 // first (flat, 8/16 B per lane) and picked up from there; results take the same way back, and the packed-real passes
 // work on the staged lines (one output bin per thread and step, both partners read from LDS).  Row pitch 33 B complex:
 // every LDS access of the kernel is conflict free.
-template<typename R> struct small_cfg { static constexpr int NT = sizeof(R) == 8 ? 128 : 256; };
+// group size of the LDS-staged kernel (lines of 32 .. 256 points), round 3 (gpurun_out/r3m/small_nt.txt, profiles/r03_bench_mid.txt): f32 in groups
+// of 128 threads instead of 256: rfft / irfft / fft at N = 128 69.3 / 67.1 / 63.8 -> 72.7 / 70.5 / 67.7 %, N = 256 70.3 / 68.5 / 65.1 -> 72.4 / 70.7 /
+// 67.6 %, N = 512 +1 .. 3, N = 64 +0 .. 3 (512 threads: the real transforms fall to 57 %).  f64 stays at 128 (64: irfft N = 512 62.7 -> 51.9 %).
+#ifndef DSC_SMALL_NT_F32
+#define DSC_SMALL_NT_F32 128
+#endif
+#ifndef DSC_SMALL_NT_F64
+#define DSC_SMALL_NT_F64 128
+#endif
+template<typename R> struct small_cfg { static constexpr int NT = sizeof(R) == 8 ? DSC_SMALL_NT_F64 : DSC_SMALL_NT_F32; };
 template<typename R, int B> constexpr size_t small_lds_bytes() { return ((size_t) (small_cfg<R>::NT / B) * 33 * B + 32 * B + 32 * B + 2) * 2 * sizeof(R); }
 
 // PAD: the input lines have a pitch of in_pitch BYTES of which in_len BYTES are valid (a packed-real line may hold an odd number of
