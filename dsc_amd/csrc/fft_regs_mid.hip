@@ -601,18 +601,25 @@ void launch_filter_len(int L, const void *s, const void *H, void *y, long long n
 #ifndef DSC_SMALL_NT_F64
 #define DSC_SMALL_NT_F64 128
 #endif
-template<typename R> struct small_cfg { static constexpr int NT = sizeof(R) == 8 ? DSC_SMALL_NT_F64 : DSC_SMALL_NT_F32; };
-template<typename R, int B> constexpr size_t small_lds_bytes() { return ((size_t) (small_cfg<R>::NT / B) * 33 * B + 32 * B + 32 * B + 2) * 2 * sizeof(R); }
+// f64 COMPLEX lines in groups of 64 threads (fft c64 L = 32 / 128 / 256: 65.5 / 64.1 / 65.0 -> 66.6 / 66.7 / 74.2 %); the f64 real transforms lose with
+// it (irfft N = 512 62.7 -> 51.9 %) and keep 128
+#ifndef DSC_SMALL_NT_F64_COMPLEX
+#define DSC_SMALL_NT_F64_COMPLEX 64
+#endif
+template<typename R, int MODE> struct small_cfg {
+    static constexpr int NT = sizeof(R) == 8 ? (MODE == DSC_MODE_C2C ? DSC_SMALL_NT_F64_COMPLEX : DSC_SMALL_NT_F64) : DSC_SMALL_NT_F32;
+};
+template<typename R, int B, int MODE> constexpr size_t small_lds_bytes() { return ((size_t) (small_cfg<R, MODE>::NT / B) * 33 * B + 32 * B + 32 * B + 2) * 2 * sizeof(R); }
 
 // PAD: the input lines have a pitch of in_pitch BYTES of which in_len BYTES are valid (a packed-real line may hold an odd number of
 // samples: the pair that straddles its end keeps the first sample only); the rest of the transform length reads as zero
 // (zero padding / cropping through n=, dsc.cpp:1990-1998, 2125-2133, 2149-2157) — e.g. frames of 200 samples transformed at 256.
 template<typename R, int B, int MODE, bool INV, bool PAD>
-__global__ __launch_bounds__(small_cfg<R>::NT) void fft_small_kernel(const void *__restrict__ in, void *__restrict__ out, long long n_lines,
+__global__ __launch_bounds__((small_cfg<R, MODE>::NT)) void fft_small_kernel(const void *__restrict__ in, void *__restrict__ out, long long n_lines,
                                                                      const cpx<R> *__restrict__ tw_full, const cpx<R> *__restrict__ tw_real,
                                                                      R scale, int in_pitch, int in_len) {
     using C = cpx<R>;
-    constexpr int NT = small_cfg<R>::NT, L = 32 * B, G = NT / B, P = 33 * B, LOGB = ilog2(B);
+    constexpr int NT = small_cfg<R, MODE>::NT, L = 32 * B, G = NT / B, P = 33 * B, LOGB = ilog2(B);
     constexpr bool REAL_IN = MODE == DSC_MODE_R2C_CAST;
     constexpr int IN_PITCH = MODE == DSC_MODE_C2R_PACKED ? L + 1 : L, OUT_PITCH = MODE == DSC_MODE_R2C_PACKED ? L + 1 : L;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -730,14 +737,14 @@ __global__ __launch_bounds__(small_cfg<R>::NT) void fft_small_kernel(const void 
 template<typename R, int B, int MODE, bool INV, bool PAD>
 void launch_small_pad(const void *in, void *out, long long n_lines, const void *tw_full, const void *tw_real, double scale, int in_pitch, int in_len,
                       hipStream_t stream) {
-    constexpr int G = small_cfg<R>::NT / B;
-    constexpr size_t lds = small_lds_bytes<R, B>();
+    constexpr int G = small_cfg<R, MODE>::NT / B;
+    constexpr size_t lds = small_lds_bytes<R, B, MODE>();
     static unsigned long long attr_devices = 0;
     if (dsc_first_use_on_device(attr_devices)) {
         DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) fft_small_kernel<R, B, MODE, INV, PAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     }
     const long long groups = (n_lines + G - 1) / G;
-    DSC_LAUNCH((fft_small_kernel<R, B, MODE, INV, PAD>), dim3((unsigned) groups), dim3(small_cfg<R>::NT), lds, stream, in, out, n_lines,
+    DSC_LAUNCH((fft_small_kernel<R, B, MODE, INV, PAD>), dim3((unsigned) groups), dim3(small_cfg<R, MODE>::NT), lds, stream, in, out, n_lines,
                        (const cpx<R> *) tw_full, (const cpx<R> *) tw_real, (R) scale, in_pitch, in_len);
 }
 // in_pitch < 0: full contiguous lines

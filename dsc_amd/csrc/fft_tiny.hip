@@ -16,7 +16,10 @@
 
 namespace {
 
-constexpr int kTinyNT = 256;
+#ifndef DSC_TINY_NT
+#define DSC_TINY_NT 256
+#endif
+constexpr int kTinyNT = DSC_TINY_NT;
 
 // W_2L^k = exp(-2 pi i k / 2L), k <= L, for 2L <= 32: a 64th root
 template<int L> __device__ constexpr double w2l_re(int k) { return root64_re(k * (32 / L)); }
