@@ -393,15 +393,19 @@ def main():
         B.dsc_timer_start(ctx)          # HIP events on the stream the kernel is launched on
         marks[0].record(cstream)
     t0 = time.perf_counter()
+    host_marks = [t0]
     for i in range(args.steps):
         step()
         if marks is not None:
             marks[i + 1].record(cstream)
+        else:
+            host_marks.append(time.perf_counter())      # dry run: the host clock stands in for the events
     if not args.dry_run:
         kernel_ms = B.dsc_timer_stop(ctx) / args.steps
     barrier_sync()
     elapsed = time.perf_counter() - t0
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)) if marks is not None else None
+    per_step = (sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)) if marks is not None
+                else sorted((host_marks[i + 1] - host_marks[i]) * 1e3 for i in range(args.steps)))
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if args.dry_run or args.backend == 'gloo' else 'cuda')

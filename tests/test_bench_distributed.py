@@ -31,10 +31,11 @@ def test_two_rank_dry_run():
     assert j['config']['global_batch'] == 2 * 8192
     # 4 steps of >= 1 ms each on the slowest rank
     assert j['ms_per_step'] >= 1.0
+    assert 1.0 <= j['min_ms'] <= j['median_ms']                       # per-step times (reference convention: the minimum)
     assert abs(j['value'] - 2 * 8192 * 65536 / (j['ms_per_step'] * 1e-3) / 1e9) / j['value'] < 1e-2
     # the reassembly phase ran for real on two gloo ranks (deterministic per-rank arrays) and proved itself
     g = j['allgather']
-    assert g['verified'] is True and g['ms'] > 0 and g['recv_GBps_per_gpu'] > 0
+    assert g['verified'] is True and g['ms'] > 0 and g['recv_GBps_per_gpu'] > 0 and g['GBps_per_link'] > 0
     assert set(g['variants']) == {'allgather', 'p2p'}              # 'ipc' needs device memory
     assert all(v['verified'] is True for v in g['variants'].values())
 
