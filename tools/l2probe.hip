@@ -41,7 +41,7 @@ __global__ void init_rows(u4 *in, long long total, int row_e) {
 
 struct params {
     const u4 *in; u4 *out; u4 *scratch; unsigned *bars, *tickets, *errs;
-    int rows, ts, tpx, delay, no_in, no_out, pair, refresh, refresh_kind, frac;
+    int rows, ts, tpx, delay, no_in, no_out, pair, refresh, refresh_kind, frac, bar_mode;
 };
 
 // IPOL / OPOL: aux bits of the input loads / output stores; APOL / RPOL: of the scratch stores / loads (1 = sc0, 2 = nt, 16 = sc1)
@@ -78,14 +78,29 @@ __global__ __launch_bounds__(T, 2) void probe(params p) {
 #pragma unroll
         for (int e = 0; e < E; ++e) dst[e] = __builtin_amdgcn_raw_buffer_load_b128(r, ((q + TS * (e * (T / 8) + p8)) * 8 + l8) * 16, 0, IPOL);
     };
+    // bar_mode 0: everybody adds to ONE counter and polls it with atomics (the team kernel's form); 1: the arrivals go to the counter, the LAST
+    // one (seen in its fetch-add's return value) publishes the generation in a flag on another line and everybody polls that flag;
+    // 2: as 0 but polling with sc1 loads; 3: as 1, polling with sc1 loads
     auto barrier = [&](bool drain) {
         target += TS;
         if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_only_barrier();
         if (tid == T - 1) {
-            l2_add(bar);
+            unsigned *flag = bar + 32;
+            if (p.bar_mode == 1 || p.bar_mode == 3) {
+                unsigned old;
+                asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(old) : "v"(bar), "v"(1u) : "memory");
+                if (old + 1 == target) asm volatile("global_store_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : : "v"(flag), "v"(target) : "memory");
+            } else {
+                l2_add(bar);
+            }
+            unsigned *watch = (p.bar_mode == 1 || p.bar_mode == 3) ? flag : bar;
             unsigned spins = 0;
-            while ((int) (l2_read(bar) - target) < 0) {
+            for (;;) {
+                unsigned seen;
+                if (p.bar_mode >= 2) asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(seen) : "v"(watch) : "memory");
+                else seen = l2_read(watch);
+                if ((int) (seen - target) >= 0) break;
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > (1u << 17)) { atomicAdd(p.errs + 2, 1u); lds[2] = 1; break; }
             }
@@ -344,13 +359,13 @@ __global__ __launch_bounds__(T, 2) void probe_pipe(params p) {
 struct state { u4 *in, *out, *scratch; unsigned *bars, *tickets, *errs; int row_e; bool pmc; };
 
 template<int IPOL, int OPOL, int APOL, int RPOL>
-void run(state &s, int ts, int tpx, const char *pol, int no_in = 0, int no_out = 0, int pair = 0, int delay = 0, int refresh = 0, int rkind = 0, int frac = 16) {
+void run(state &s, int ts, int tpx, const char *pol, int no_in = 0, int no_out = 0, int pair = 0, int delay = 0, int refresh = 0, int rkind = 0, int frac = 16, int bar_mode = 0) {
     const int row_e = kTaskE * ts;
     if (s.row_e != row_e) {
         hipLaunchKernelGGL(init_rows, dim3((unsigned) (kTotalE / 256)), dim3(256), 0, 0, s.in, kTotalE, row_e);
         s.row_e = row_e;
     }
-    params p{s.in, s.out, s.scratch, s.bars, s.tickets, s.errs, (int) (kTotalE / row_e), ts, tpx, delay, no_in, no_out, pair, refresh, rkind, frac};
+    params p{s.in, s.out, s.scratch, s.bars, s.tickets, s.errs, (int) (kTotalE / row_e), ts, tpx, delay, no_in, no_out, pair, refresh, rkind, frac, bar_mode};
     const int wg_per_xcd = ts * tpx, wpc = (wg_per_xcd + 31) / 32;
     const int lds = wpc == 1 ? 96 * 1024 : 48 * 1024;
     auto k = probe<IPOL, OPOL, APOL, RPOL>;
@@ -372,8 +387,8 @@ void run(state &s, int ts, int tpx, const char *pol, int no_in = 0, int no_out =
     static int n = 0;
     // bytes through the XCD's L2 between two writes of one scratch line: every team's in + out + scratch of one row (a pair shares)
     const double slot_kib = ts * 64.0 * frac / 16, reuse_mib = tpx * (ts * 64.0 * (2 - no_in - no_out) + slot_kib) / 1024.0;
-    printf("variant %2d: frac %2d/16 slot %5.0f KiB  teams/XCD %2d%s  between rewrites %5.2f MiB  pol %-22s%s%s refresh %d%s delay %d  %8.3f ms  %6.0f GB/s  stale %u uneven %u timeouts %u\n", n++, frac,
-           slot_kib, tpx, pair ? " (pairs share)" : "", reuse_mib, pol, no_in ? " NO-IN" : "", no_out ? " NO-OUT" : "", refresh, rkind == 1 ? " (atomic or 0)" : rkind == 2 ? " (sc0 sc1 loads)" : "", delay, best, 2.0 * kTotalE * 16 / best / 1e6, errs[0],
+    printf("variant %2d: frac %2d/16 slot %5.0f KiB  teams/XCD %2d%s  between rewrites %5.2f MiB  pol %-22s%s%s refresh %d%s barrier %d delay %d  %8.3f ms  %6.0f GB/s  stale %u uneven %u timeouts %u\n", n++, frac,
+           slot_kib, tpx, pair ? " (pairs share)" : "", reuse_mib, pol, no_in ? " NO-IN" : "", no_out ? " NO-OUT" : "", refresh, rkind == 1 ? " (atomic or 0)" : rkind == 2 ? " (sc0 sc1 loads)" : "", bar_mode, delay, best, 2.0 * kTotalE * 16 / best / 1e6, errs[0],
            errs[1], errs[2]);
     fflush(stdout);
 }
@@ -540,6 +555,15 @@ int main() {
             run_split<1>(s, 8, 8, no, no); run_split<2>(s, 8, 8, no, no); run_split<4>(s, 8, 8, no, no);
         }
         run_split<2>(s, 32, 2, 1, 1, 0); run_split<4>(s, 32, 2, 1, 1, 0); run_split<2>(s, 32, 2, 0, 0, 0); run_split<4>(s, 32, 2, 0, 0, 0);
+    }
+    if (want("E9")) {
+        printf("# E9: the team barrier itself: 0 = one counter, atomic polls; 1 = last arrival publishes a flag, atomic polls; 2 / 3 = the same with sc1-load polls\n");
+        for (int bm : {0, 1, 2, 3}) {
+            run<2, 2, 0, 16>(s, 32, 1, "in nt / out nt", 1, 1, 0, 0, 0, 0, 16, bm);
+            run<2, 2, 0, 16>(s, 32, 2, "in nt / out nt", 1, 1, 1, 0, 0, 0, 16, bm);
+            run<2, 2, 0, 16>(s, 32, 2, "in nt / out nt", 0, 0, 1, 0, 0, 0, 16, bm);
+            run<2, 2, 0, 16>(s, 8, 8, "in nt / out nt", 0, 0, 1, 0, 0, 0, 16, bm);
+        }
     }
     if (want("E8")) {
         printf("# E8: the sliced exchange as a pipeline (K slices through a ring of S slots per team, consumers LAG slices behind)\n");
