@@ -99,6 +99,14 @@ template<typename R, int B, bool TWO, int V = 0> struct mid_cfg {
                                  : (TWO ? DSC_MID_NT_F32_TWO : B >= 32 ? 1024 : B == 16 ? 512 : B == 8 ? (V == 1 ? DSC_MID_NT_F32_B8_FILTER : DSC_MID_NT_F32_B8)
                                                                                   : B == 4 ? DSC_MID_NT_F32_B4 : (PACKED ? DSC_MID_NT_F32_B2 : 256));
     static constexpr int G = NT / T;                 // lines per workgroup
+    // f64 lines of 16384 points: ONE 512-thread group per CU (131 KiB plane) — nothing to overlap its load / compute / store phases
+    // with.  PIPE: the group is persistent (lines blockIdx.x, + gridDim.x, ...) and requests its next line into the registers the stores
+    // (complex, inverse real) or the last staging write (forward real) have just freed, the way the 65536-point kernels do.
+#ifdef DSC_MID_NO_PIPE
+    static constexpr bool PIPE = false;
+#else
+    static constexpr bool PIPE = DP && !TWO && B == 16 && V == 0;
+#endif
     static constexpr int WAVES_PER_EU = DP ? 2 : (TWO ? 2 : (B >= 8 || PACKED) ? 4 : 2);   // f32: <= 128 VGPRs where two 512-thread groups share a CU
     static constexpr int P1 = 33;                    // exchange-1 row pitch (values): odd
     static constexpr int P2 = PACKED ? B : B + 1;    // last-exchange row pitch
@@ -253,8 +261,10 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
 
     const int tid = threadIdx.x;
     const int g = T >= 64 ? __builtin_amdgcn_readfirstlane(tid / T) : tid / T;      // line within the group
-    const int t = tid - g * T;
-    const long long line0 = (long long) blockIdx.x * G;
+    int t = tid - g * T;
+    constexpr bool PIPE = cfg::PIPE;
+    static_assert(!PIPE || G == 1, "the persistent form walks single lines");
+    long long line0 = PIPE ? (long long) blockIdx.x : (long long) blockIdx.x * G;
     const long long left = n_lines - line0;
     const int n_valid = left < G ? (int) left : G;                  // lines past the end read zeros, their stores are dropped
     constexpr int in_pitch = MODE == DSC_MODE_C2R_PACKED ? L + 1 : L;
@@ -267,23 +277,28 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
     constexpr int LOADP = kComplex ? kStream : kCached;
     constexpr int STOREP = kComplex || (MODE == DSC_MODE_C2R_PACKED && !TWO) ? kStream : kCached;
     const int pitch_b = PAD ? in_pitch_b : in_pitch * IB;
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
-        (void *) ((const char *) in + line0 * pitch_b), 0, PAD ? (n_valid - 1) * pitch_b + in_len_b : n_valid * in_pitch * IB, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *) (out + line0 * out_pitch), 0, n_valid * out_pitch * CB, 0x00020000);
-    const int vin = g * pitch_b + t * IB;                          // byte offset of element t of this thread's line
+    auto in_rsrc = [&](long long first) {
+        return __builtin_amdgcn_make_buffer_rsrc((void *) ((const char *) in + first * pitch_b), 0,
+                                                 PAD ? (n_valid - 1) * pitch_b + in_len_b : n_valid * in_pitch * IB, 0x00020000);
+    };
+    __amdgpu_buffer_rsrc_t rin = in_rsrc(line0);
+    __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *) (out + line0 * out_pitch), 0, n_valid * out_pitch * CB, 0x00020000);
+    int vin = g * pitch_b + t * IB;                                // byte offset of element t of this thread's line
     // element `idx` of the line (units of IB bytes); with PAD, elements past the valid length read zero (their offset is
-    // pushed out of the descriptor's range) and a sample pair cut by an odd length keeps its real part only
-    auto load_elem = [&](int idx) -> C {
+    // pushed out of the descriptor's range; one line per group: the descriptor ends with the line's valid bytes and does that by
+    // itself) and a sample pair cut by an odd length keeps its real part only
+    auto load_from = [&](const __amdgpu_buffer_rsrc_t &rs, int idx) -> C {
         constexpr int kOut = 0x7f000000;
         if constexpr (MODE == DSC_MODE_R2C_CAST) {
-            return buf_load_real<LOADP>(rin, (!PAD || (t + idx) * IB < in_len_b) ? vin : kOut, idx * IB, R{});
+            return buf_load_real<LOADP>(rs, (!PAD || G == 1 || (t + idx) * IB < in_len_b) ? vin : kOut, idx * IB, R{});
         } else {
-            C val = buf_load<LOADP>(rin, (!PAD || (t + idx) * CB < in_len_b) ? vin : kOut, idx * CB, R{});
+            C val = buf_load<LOADP>(rs, (!PAD || G == 1 || (t + idx) * CB < in_len_b) ? vin : kOut, idx * CB, R{});
             if (PAD && MODE == DSC_MODE_R2C_PACKED && (t + idx) * CB + CB > in_len_b) val.y = (R) 0;
             return val;
         }
     };
-    const int vout = (g * out_pitch + t) * CB;
+    auto load_elem = [&](int idx) -> C { return load_from(rin, idx); };
+    int vout = (g * out_pitch + t) * CB;
     R *stage = plane + g * SP;
 
     for (int i = tid; i < cfg::TABLE; i += NT) wtab[i] = tw_full[(long long) i * cfg::TABLE_STRIDE];    // W_1024^m = W_L^{B m}
@@ -297,6 +312,18 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
     if constexpr (MODE != DSC_MODE_C2R_PACKED || !PAIR_ONCE) {
 #pragma unroll
         for (int j1 = 0; j1 < 32; ++j1) v[j1] = load_elem(T * j1);                           // z[T j1 + t]
+    }
+    static_assert(!(PIPE && PAIR_ONCE), "the persistent form requests the whole next line into v");
+    do {
+    const long long next_line = line0 + (long long) gridDim.x;
+    const bool more = PIPE && next_line < n_lines;                  // uniform
+    const __amdgpu_buffer_rsrc_t rnext = in_rsrc(more ? next_line : line0);
+    if constexpr (PIPE) {
+        // Everything derived from the thread id is loop invariant: hipcc would hoist it out of the persistent loop (dozens of LDS and
+        // buffer addresses) and spill it.  An opaque copy per line keeps the address arithmetic next to its use.
+        asm volatile("" : "+v"(t));
+        vin = g * pitch_b + t * IB;
+        vout = (g * out_pitch + t) * CB;
     }
     if constexpr (MODE == DSC_MODE_C2R_PACKED && !PAIR_ONCE) {
         // Z[k] = (a + conj b)/2 + wq (a - conj b), a = Y[k], b = Y[L-k], wq = (i/2) conj(W_2L^k), for the
@@ -383,12 +410,21 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
 
     if constexpr (MODE != DSC_MODE_R2C_PACKED) {
 #pragma unroll
-        for (int i = 0; i < CPT; ++i)
+        for (int i = 0; i < CPT; ++i) {
 #pragma unroll
             for (int p = 0; p < B; ++p) {
                 const C r = v[i * B + p];
                 buf_store<STOREP>(C{r.x * scale, r.y * scale}, rout, vout, (T * i + COLS * brev(p, LOGB)) * CB);
             }
+            if constexpr (PIPE) {                                  // the next line's elements into the registers just stored
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+#pragma unroll
+                    for (int p = 0; p < B; ++p) v[i * B + p] = load_from(rnext, T * (i * B + p));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     } else {
         // packed-real post-pass (dsc_fft.h:199-225), one thread per PAIR (k, L-k), k = t + T i < L/2,
         // plus k = L/2 (thread 0).  a = Z[k], b = Z[L-k]:
@@ -412,6 +448,14 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
 #pragma unroll
             for (int p = 0; p < B; ++p) up[T * i + COLS * brev(p, LOGB)] = v[i * B + p].y;
         if (t == 0) stage[L] = v[0].y;
+        if constexpr (PIPE) {                                      // v is dead from here: the next line travels under the post-pass,
+            __builtin_amdgcn_sched_barrier(0);                     // its first half now, the rest as ax / bx free their registers
+            if (more) {
+#pragma unroll
+                for (int j1 = 0; j1 < 16; ++j1) v[j1] = load_from(rnext, T * j1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         lds_barrier();
         const int dn_voff = (g * out_pitch + (L - 15 * T) - t) * CB;
 #pragma unroll
@@ -426,12 +470,26 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
             if (i == 0 && t == 0) { xk.y = (R) 0; xm.y = (R) 0; }           // dsc_fft.h:221-225 stores exact zeros
             buf_store<STOREP>(C{xk.x * scale, xk.y * scale}, rout, vout, T * i * CB);
             buf_store<STOREP>(C{xm.x * scale, xm.y * scale}, rout, dn_voff, T * (15 - i) * CB);
+            if constexpr (PIPE) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) v[16 + i] = load_from(rnext, T * (16 + i));
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (t == 0) {                                                     // k = L/2: a = b, W_2L^{L/2} = -i
             const R ay = stage[L / 2];
             buf_store<STOREP>(C{amx * scale, -ay * scale}, rout, vout, (L / 2) * CB);
         }
     }
+    if constexpr (PIPE) {
+        if (!more) break;
+        line0 = next_line;
+        rin = rnext;
+        rout = __builtin_amdgcn_make_buffer_rsrc((void *) (out + line0 * out_pitch), 0, out_pitch * CB, 0x00020000);
+        // no barrier here: the passes end with one (the inverse pre-pass may write the staging plane at once), and the forward
+        // post-pass's staging reads are followed by the barrier in front of the next line's passes
+    }
+    } while (PIPE);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -775,7 +833,15 @@ void launch_pad(const void *in, void *out, long long n_lines, const void *tw_ful
     if (dsc_first_use_on_device(attr_devices)) {
         DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) fft_mid_kernel<R, B, TWO, MODE, INV, PAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     }
-    const long long groups = (n_lines + cfg::G - 1) / cfg::G;
+    long long groups = (n_lines + cfg::G - 1) / cfg::G;
+    if (cfg::PIPE) {                                        // persistent: one workgroup per CU walks the lines
+        static int cus[64];
+        int dev = 0;
+        DSC_KERNEL_CHECK(hipGetDevice(&dev));
+        dev &= 63;
+        if (cus[dev] == 0) DSC_KERNEL_CHECK(hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev));
+        if (groups > cus[dev]) groups = cus[dev];
+    }
     DSC_LAUNCH((fft_mid_kernel<R, B, TWO, MODE, INV, PAD>), dim3((unsigned) groups), dim3(cfg::NT), lds, stream, (const cpx<R> *) in,
                        (cpx<R> *) out, n_lines, (const cpx<R> *) tw_full, (const cpx<R> *) tw_real, (R) scale, in_pitch_b, in_len_b);
 }

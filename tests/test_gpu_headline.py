@@ -455,6 +455,53 @@ def test_mid_sizes_padded_and_cropped(dsc, dt, n):
             assert_close(b.numpy()[0], port.irfft(Y[0], bins), what=f'irfft bins={bins} ls={ls}')
 
 
+def test_f64_lines_of_16384_points_more_lines_than_workgroups(dsc):
+    """f64 lines of 16384 complex points run in a PERSISTENT form of fft_mid_kernel: one group per CU walks lines blockIdx.x,
+    + gridDim.x, ... and requests its next line while it stores the current one.  600 lines on 256 CUs: every group walks two or
+    three lines (a ragged last round); every element of every line against numpy (f64, 1e-12 of the row's largest value), full
+    lines and padded / cropped ones (the descriptor of a single line ends with its valid bytes), one row of each against the oracle."""
+    from oracle import port
+    rng = np.random.default_rng(16384)
+    rows, n = 600, 32768
+
+    def worst(got, want):
+        return float(np.max(np.abs(got - want) / np.max(np.abs(want), axis=1, keepdims=True)))
+
+    x = rng.standard_normal((rows, n))
+    X = dsc.rfft(dsc.from_numpy(x))
+    assert dsc.last_fft_path() == 'regs_mid'
+    wX = np.fft.rfft(x, axis=-1)
+    assert worst(X.numpy(), wX) <= 1e-12
+    assert_close(X.numpy()[rows - 1], port.rfft(x[rows - 1]), what='f64 rfft, last line')
+    back = dsc.irfft(X)
+    assert dsc.last_fft_path() == 'regs_mid'
+    assert worst(back.numpy(), x) <= 1e-12
+    z = rng.standard_normal((rows, n // 2)) + 1j * rng.standard_normal((rows, n // 2))
+    Z = dsc.fft(dsc.from_numpy(z))
+    assert dsc.last_fft_path() == 'regs_mid'
+    assert worst(Z.numpy(), np.fft.fft(z, axis=-1)) <= 1e-12
+    zb = dsc.ifft(Z)
+    assert worst(zb.numpy(), z) <= 1e-12
+    F = dsc.fft(dsc.from_numpy(x[:, :n // 2].copy()))        # real input, cast on load
+    assert worst(F.numpy(), np.fft.fft(x[:, :n // 2], axis=-1)) <= 1e-12
+    del X, back, Z, zb, F
+    for ls in (n - 3001, n + 64):                            # shorter (odd: cuts a sample pair) and longer axis than the transform
+        xs = rng.standard_normal((rows, ls))
+        got = dsc.rfft(dsc.from_numpy(xs), n=n)
+        assert dsc.last_fft_path() == 'regs_mid'
+        assert worst(got.numpy(), np.fft.rfft(xs, n=n, axis=-1)) <= 1e-12
+        assert_close(got.numpy()[257], port.rfft(xs[257], n), what=f'f64 rfft n={n} ls={ls}')
+        cs = xs[:, :ls // 2] + 1j * xs[:, ls // 2:2 * (ls // 2)]
+        gc = dsc.fft(dsc.from_numpy(cs), n=n // 2)
+        assert worst(gc.numpy(), np.fft.fft(cs, n=n // 2, axis=-1)) <= 1e-12
+        bins = n // 2 + 1
+        Y = cs[:, :min(cs.shape[1], bins + 5)]
+        b = dsc.irfft(dsc.from_numpy(np.ascontiguousarray(Y)), n=bins)
+        assert dsc.last_fft_path() == 'regs_mid'
+        assert_close(b.numpy()[511], port.irfft(Y[511], bins), what=f'f64 irfft bins={bins} ls={Y.shape[1]}')
+        assert_close(b.numpy()[3], port.irfft(Y[3], bins), what=f'f64 irfft bins={bins} ls={Y.shape[1]}')
+
+
 def test_fused_l2_team_kernel_many_rows(dsc):
     """fft_xcd_fused.hip (65536-point complex rows / real length 131072, f32 and f64): more rows than teams, so that every team walks
     several rows (claimed from the global counter, published at a team barrier) and the scratch rows are reused; all four
