@@ -309,6 +309,11 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
     // tools/bench_mid.py on one box) and the f64 forms spill MORE with it (0 - 31 -> 31 - 51: hipcc starts all sixteen pairs at once);
     // both keep the two-exchange form.
     constexpr bool PAIR_ONCE = sizeof(R) == 4 && !TWO && B == 16;
+#ifdef DSC_MID_OLD_POST
+    constexpr bool POST_ONCE = false;
+#else
+    constexpr bool POST_ONCE = !TWO;                 // the forward post-pass that moves only the upper halves (see there)
+#endif
     if constexpr (MODE != DSC_MODE_C2R_PACKED || !PAIR_ONCE) {
 #pragma unroll
         for (int j1 = 0; j1 < 32; ++j1) v[j1] = load_elem(T * j1);                           // z[T j1 + t]
@@ -425,6 +430,51 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+    } else if constexpr (POST_ONCE) {
+        // packed-real post-pass (dsc_fft.h:199-225), three-pass lines, round 3.  The column layout leaves thread t with the bins
+        // t + T m, m = 0 .. 31 (COLS = T CPT: m = i + CPT brev(p)) — its sixteen lower bins k AND sixteen upper ones, and the partners
+        // L - k of its lower bins are the UPPER bins of thread T - t.  So only the upper halves travel: both components at once (L reals:
+        // the plane holds them), ONE barrier, half the LDS traffic of "everybody stages all 32 bins, twice", and no second 32-value array.
+        //   a = Z[k] (own register), b = Z[L-k]:  s = a + conj b, d = a - conj b, wq = -(i/2) W_2L^k:  X[k] = s/2 + wq d,  X[L-k] = conj(s/2 - wq d)
+        const C wbase = tw_real[t];
+        auto reg_of = [](int m) constexpr { return (m % CPT) * B + brev(m / CPT, LOGB); };      // register that holds bin t + T m
+        R *wr_x = stage + t, *wr_y = stage + L / 2 + t;                 // [T (m - 16)] = bin t + T m - L/2
+        const R *rd_x = stage + (L / 2 - 15 * T) - t;                   // [T (15 - m)] = bin (L - k) - L/2, k = t + T m
+        const R *rd_y = rd_x + L / 2;
+#pragma unroll
+        for (int m = 16; m < 32; ++m) { wr_x[T * (m - 16)] = v[reg_of(m)].x; wr_y[T * (m - 16)] = v[reg_of(m)].y; }
+        const C zmid = v[reg_of(16)];                                   // thread 0: bin L/2, which pairs with itself
+        if constexpr (PIPE) {                                           // the upper half is dead: the next line's elements into its registers
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+#pragma unroll
+                for (int m = 16; m < 32; ++m) v[reg_of(m)] = load_from(rnext, T * reg_of(m));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        lds_barrier();
+        const int dn_voff = (g * out_pitch + (L - 15 * T) - t) * CB;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const C a = v[reg_of(m)];
+            C b = C{rd_x[T * (15 - m)], rd_y[T * (15 - m)]};
+            if (m == 0 && t == 0) b = a;                                  // Z[L] := Z[0]
+            const C w = cmul(wbase, C{(R) root64_re(m), (R) root64_im(m)});        // W_2L^{t + T m} = W_2L^t W_64^m
+            const R wqx = (R) 0.5 * w.y, wqy = (R) -0.5 * w.x;
+            const R sx = a.x + b.x, sy = a.y - b.y, dx = a.x - b.x, dy = a.y + b.y;
+            const R wdx = dx * wqx - dy * wqy, wdy = dx * wqy + dy * wqx;
+            C xk = C{(R) 0.5 * sx + wdx, (R) 0.5 * sy + wdy};
+            C xm = C{(R) 0.5 * sx - wdx, wdy - (R) 0.5 * sy};
+            if (m == 0 && t == 0) { xk.y = (R) 0; xm.y = (R) 0; }           // dsc_fft.h:221-225 stores exact zeros
+            buf_store<STOREP>(C{xk.x * scale, xk.y * scale}, rout, vout, T * m * CB);
+            buf_store<STOREP>(C{xm.x * scale, xm.y * scale}, rout, dn_voff, T * (15 - m) * CB);
+            if constexpr (PIPE) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) v[reg_of(m)] = load_from(rnext, T * reg_of(m));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (t == 0) buf_store<STOREP>(C{zmid.x * scale, -zmid.y * scale}, rout, vout, (L / 2) * CB);    // k = L/2: a = b, W_2L^{L/2} = -i
     } else {
         // packed-real post-pass (dsc_fft.h:199-225), one thread per PAIR (k, L-k), k = t + T i < L/2,
         // plus k = L/2 (thread 0).  a = Z[k], b = Z[L-k]:
