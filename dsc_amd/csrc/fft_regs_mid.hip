@@ -274,8 +274,16 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
     // ones from streaming their (aligned) stores at L >= 2048; everything that touches rows of L + 1 bins, and the
     // forward real transform as a whole, is faster cached (see fft_regs_common.h)
     constexpr bool kComplex = MODE == DSC_MODE_C2C || MODE == DSC_MODE_R2C_CAST;
-    constexpr int LOADP = kComplex ? kStream : kCached;
-    constexpr int STOREP = kComplex || (MODE == DSC_MODE_C2R_PACKED && !TWO) ? kStream : kCached;
+    // the persistent f64 lines (PIPE): streaming loads + cached stores measured best for the real transforms (tools/r03_call_p.sh:
+    // rfft 55.6 -> 56.2 %, irfft 50.9 -> 52.4 %; streaming stores: rfft 52 %)
+#ifndef DSC_MID_PIPE_REAL_LOAD
+#define DSC_MID_PIPE_REAL_LOAD kStream
+#endif
+#ifndef DSC_MID_PIPE_REAL_STORE
+#define DSC_MID_PIPE_REAL_STORE kCached
+#endif
+    constexpr int LOADP = kComplex ? kStream : cfg::PIPE ? DSC_MID_PIPE_REAL_LOAD : kCached;
+    constexpr int STOREP = kComplex || (MODE == DSC_MODE_C2R_PACKED && !TWO) ? kStream : (cfg::PIPE && MODE == DSC_MODE_R2C_PACKED) ? DSC_MID_PIPE_REAL_STORE : kCached;
     const int pitch_b = PAD ? in_pitch_b : in_pitch * IB;
     auto in_rsrc = [&](long long first) {
         return __builtin_amdgcn_make_buffer_rsrc((void *) ((const char *) in + first * pitch_b), 0,
@@ -312,7 +320,9 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
 #ifdef DSC_MID_OLD_POST
     constexpr bool POST_ONCE = false;
 #else
-    constexpr bool POST_ONCE = !TWO;                 // the forward post-pass that moves only the upper halves (see there)
+    // measured (tools/r03_call_o.sh): f32 + 0 - 1.7 points at every three-pass length; f64 lines of 2048 - 8192 points lose 1 - 2 points
+    // with it (they keep the two-exchange form), the persistent f64 lines of 16384 points need its registers (49 -> 55 %)
+    constexpr bool POST_ONCE = !TWO && (sizeof(R) == 4 || B == 16);
 #endif
     if constexpr (MODE != DSC_MODE_C2R_PACKED || !PAIR_ONCE) {
 #pragma unroll
@@ -582,74 +592,137 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO, 1>::NT), (mid_cfg<R, B, TWO, 1>
     __syncthreads();
     mid_passes<R, B, TWO, false, 1>(v, plane, wtab, tw_full, g, t, tid);  // v[i B + p] = Z[(t + T i) + COLS brev(p)]
 
-    // ---- the pair (k, L-k), k = t + T i, i < 16 (plus k = L/2 in thread 0): a = Z[k], b = Z[L-k] through the staging plane
-    const C wbase = tw_real[t];
-    R ax[16], bx[16], amx = (R) 0;
-    R *up = stage + t;                          // up[T i]        = stage[k]
-    R *dn = stage + (L - 15 * T) - t;           // dn[T (15 - i)] = stage[L - k]
+#ifdef DSC_MID_OLD_FILTER_PAIRS
+    constexpr bool ONCE = false;
+#else
+    constexpr bool ONCE = !TWO;
+#endif
+    if constexpr (ONCE) {
+        // ---- three-pass lines, round 3.  The column layout leaves thread t with the bins t + T m, m = 0 .. 31: its sixteen lower bins k
+        // and sixteen upper ones; the partners L - k of its lower bins are upper bins of thread T - t.  Only the upper halves travel, both
+        // components at once (slot of upper bin b: b - L/2; x plane [0, L/2), y plane [L/2, L)): write them, ONE barrier, then per pair
+        // read b = Z[L-k], packed-real pass, times (H[k], H[L-k]), inverse pre-pass, keep Z'[k] — the inverse passes want it in register
+        // m, the load layout — and put Z'[L-k] back into the slot it came from (read by this thread only: no barrier); second barrier,
+        // everybody collects its upper half.  Half the LDS traffic and two barriers instead of five (the form below).
+        const C wbase = tw_real[t];
+        auto reg_of = [](int m) constexpr { return (m % CPT) * B + brev(m / CPT, LOGB); };      // register that holds bin t + T m
+        R *own_x = stage + t, *own_y = stage + L / 2 + t;                 // [T (m - 16)]: slot of the own upper bin t + T m
+        R *par_x = stage + (L / 2 - 15 * T) - t;                          // [T (15 - m)]: slot of L - k, k = t + T m
+        R *par_y = par_x + L / 2;
 #pragma unroll
-    for (int i = 0; i < CPT; ++i)
+        for (int m = 16; m < 32; ++m) { own_x[T * (m - 16)] = v[reg_of(m)].x; own_y[T * (m - 16)] = v[reg_of(m)].y; }
+        const C zm0 = v[reg_of(16)];                                      // thread 0: bin L/2, which pairs with itself
+        lds_barrier();
+        C z[32];
+        const int hm_voff = ((L - 15 * T) - t) * CB;
 #pragma unroll
-        for (int p = 0; p < B; ++p) up[T * i + COLS * brev(p, LOGB)] = v[i * B + p].x;
-    if (t == 0) stage[L] = v[0].x;
-    lds_barrier();
+        for (int m = 0; m < 16; ++m) {
+            const C za = v[reg_of(m)];
+            C zb = C{par_x[T * (15 - m)], par_y[T * (15 - m)]};
+            if (m == 0 && t == 0) zb = za;                                // Z[L] := Z[0] (the slot read is somebody else's: ignored)
+            const C w = cmul(wbase, C{(R) root64_re(m), (R) root64_im(m)});            // W_2L^{t + T m}
+            // forward: X[k] = s/2 + wq d, X[L-k] = conj(s/2 - wq d), wq = -(i/2) w          (dsc_fft.h:199-225)
+            R sx = za.x + zb.x, sy = za.y - zb.y, dx = za.x - zb.x, dy = za.y + zb.y;
+            R wqx = (R) 0.5 * w.y, wqy = (R) -0.5 * w.x;
+            R wdx = dx * wqx - dy * wqy, wdy = dx * wqy + dy * wqx;
+            C xk = C{(R) 0.5 * sx + wdx, (R) 0.5 * sy + wdy};
+            C xm = C{(R) 0.5 * sx - wdx, wdy - (R) 0.5 * sy};
+            if (m == 0 && t == 0) { xk.y = (R) 0; xm.y = (R) 0; }
+            C a = cmul(xk, buf_load<kCached>(rh, t * CB, T * m * CB, R{}));
+            C b = cmul(xm, buf_load<kCached>(rh, hm_voff, T * (15 - m) * CB, R{}));
+            if (m == 0 && t == 0) { a.y = (R) 0; b.y = (R) 0; }                         // dsc_fft.h:227-228: real parts only at k = 0, L
+            // inverse: Z'[k] = s/2 + wq' d, Z'[L-k] = conj(s/2 - wq' d), wq' = (i/2) conj(w)  (dsc_fft.h:194-228)
+            sx = a.x + b.x; sy = a.y - b.y; dx = a.x - b.x; dy = a.y + b.y;
+            wqx = (R) 0.5 * w.y; wqy = (R) 0.5 * w.x;
+            wdx = dx * wqx - dy * wqy; wdy = dx * wqy + dy * wqx;
+            z[m] = C{(R) 0.5 * sx + wdx, (R) 0.5 * sy + wdy};
+            if (!(m == 0 && t == 0)) {                                    // Z'[L] is no bin
+                par_x[T * (15 - m)] = (R) 0.5 * sx - wdx;
+                par_y[T * (15 - m)] = wdy - (R) 0.5 * sy;
+            }
+        }
+        if (t == 0) {                                                     // k = L/2: X = conj Z, then Z' = conj(X H): slot 0, nobody's partner
+            const C ym = cmul(C{zm0.x, -zm0.y}, buf_load<kCached>(rh, (L / 2) * CB, 0, R{}));
+            stage[0] = ym.x;
+            stage[L / 2] = -ym.y;
+        }
+        lds_barrier();
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { ax[i] = up[T * i]; bx[i] = dn[T * (15 - i)]; }
-    if (t == 0) amx = stage[L / 2];
-    lds_barrier();
+        for (int j = 0; j < 16; ++j) z[16 + j] = C{own_x[T * j], own_y[T * j]};
+        lds_barrier();
 #pragma unroll
-    for (int i = 0; i < CPT; ++i)
-#pragma unroll
-        for (int p = 0; p < B; ++p) up[T * i + COLS * brev(p, LOGB)] = v[i * B + p].y;
-    if (t == 0) stage[L] = v[0].y;
-    lds_barrier();
-    // Every staging slot is read by exactly one thread — the one that owns the pair — so the real parts of the results go
-    // back into the same slots at once (no barrier, and only the imaginary parts stay in registers).
-    R zky[16], zmy[16];
-    C zmid = C{(R) 0, (R) 0};
-    const int hm_voff = ((L - 15 * T) - t) * CB;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const R ay = up[T * i], by = dn[T * (15 - i)];
-        const C w = cmul(wbase, C{(R) root64_re(i), (R) root64_im(i)});            // W_2L^{t + T i}
-        // forward: X[k] = s/2 + wq d, X[L-k] = conj(s/2 - wq d), wq = -(i/2) w          (dsc_fft.h:199-225)
-        R sx = ax[i] + bx[i], sy = ay - by, dx = ax[i] - bx[i], dy = ay + by;
-        R wqx = (R) 0.5 * w.y, wqy = (R) -0.5 * w.x;
-        R wdx = dx * wqx - dy * wqy, wdy = dx * wqy + dy * wqx;
-        C xk = C{(R) 0.5 * sx + wdx, (R) 0.5 * sy + wdy};
-        C xm = C{(R) 0.5 * sx - wdx, wdy - (R) 0.5 * sy};
-        if (i == 0 && t == 0) { xk.y = (R) 0; xm.y = (R) 0; }
-        // times the filter
-        C a = cmul(xk, buf_load<kCached>(rh, t * CB, T * i * CB, R{}));
-        C b = cmul(xm, buf_load<kCached>(rh, hm_voff, T * (15 - i) * CB, R{}));
-        if (i == 0 && t == 0) { a.y = (R) 0; b.y = (R) 0; }                         // dsc_fft.h:227-228: real parts only at k = 0, L
-        // inverse: Z'[k] = s/2 + wq' d, Z'[L-k] = conj(s/2 - wq' d), wq' = (i/2) conj(w)  (dsc_fft.h:194-228)
-        sx = a.x + b.x; sy = a.y - b.y; dx = a.x - b.x; dy = a.y + b.y;
-        wqx = (R) 0.5 * w.y; wqy = (R) 0.5 * w.x;
-        wdx = dx * wqx - dy * wqy; wdy = dx * wqy + dy * wqx;
-        up[T * i] = (R) 0.5 * sx + wdx;                                             // Re Z'[k]
-        dn[T * (15 - i)] = (R) 0.5 * sx - wdx;                                      // Re Z'[L-k]
-        zky[i] = (R) 0.5 * sy + wdy;
-        zmy[i] = wdy - (R) 0.5 * sy;
+        for (int j = 0; j < 32; ++j) v[j] = z[j];                         // v[j1] = Z'[T j1 + t]
+    } else {
+        // ---- the pair (k, L-k), k = t + T i, i < 16 (plus k = L/2 in thread 0): a = Z[k], b = Z[L-k] through the staging plane
+        const C wbase = tw_real[t];
+        R ax[16], bx[16], amx = (R) 0;
+        R *up = stage + t;                          // up[T i]        = stage[k]
+        R *dn = stage + (L - 15 * T) - t;           // dn[T (15 - i)] = stage[L - k]
+    #pragma unroll
+        for (int i = 0; i < CPT; ++i)
+    #pragma unroll
+            for (int p = 0; p < B; ++p) up[T * i + COLS * brev(p, LOGB)] = v[i * B + p].x;
+        if (t == 0) stage[L] = v[0].x;
+        lds_barrier();
+    #pragma unroll
+        for (int i = 0; i < 16; ++i) { ax[i] = up[T * i]; bx[i] = dn[T * (15 - i)]; }
+        if (t == 0) amx = stage[L / 2];
+        lds_barrier();
+    #pragma unroll
+        for (int i = 0; i < CPT; ++i)
+    #pragma unroll
+            for (int p = 0; p < B; ++p) up[T * i + COLS * brev(p, LOGB)] = v[i * B + p].y;
+        if (t == 0) stage[L] = v[0].y;
+        lds_barrier();
+        // Every staging slot is read by exactly one thread — the one that owns the pair — so the real parts of the results go
+        // back into the same slots at once (no barrier, and only the imaginary parts stay in registers).
+        R zky[16], zmy[16];
+        C zmid = C{(R) 0, (R) 0};
+        const int hm_voff = ((L - 15 * T) - t) * CB;
+    #pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const R ay = up[T * i], by = dn[T * (15 - i)];
+            const C w = cmul(wbase, C{(R) root64_re(i), (R) root64_im(i)});            // W_2L^{t + T i}
+            // forward: X[k] = s/2 + wq d, X[L-k] = conj(s/2 - wq d), wq = -(i/2) w          (dsc_fft.h:199-225)
+            R sx = ax[i] + bx[i], sy = ay - by, dx = ax[i] - bx[i], dy = ay + by;
+            R wqx = (R) 0.5 * w.y, wqy = (R) -0.5 * w.x;
+            R wdx = dx * wqx - dy * wqy, wdy = dx * wqy + dy * wqx;
+            C xk = C{(R) 0.5 * sx + wdx, (R) 0.5 * sy + wdy};
+            C xm = C{(R) 0.5 * sx - wdx, wdy - (R) 0.5 * sy};
+            if (i == 0 && t == 0) { xk.y = (R) 0; xm.y = (R) 0; }
+            // times the filter
+            C a = cmul(xk, buf_load<kCached>(rh, t * CB, T * i * CB, R{}));
+            C b = cmul(xm, buf_load<kCached>(rh, hm_voff, T * (15 - i) * CB, R{}));
+            if (i == 0 && t == 0) { a.y = (R) 0; b.y = (R) 0; }                         // dsc_fft.h:227-228: real parts only at k = 0, L
+            // inverse: Z'[k] = s/2 + wq' d, Z'[L-k] = conj(s/2 - wq' d), wq' = (i/2) conj(w)  (dsc_fft.h:194-228)
+            sx = a.x + b.x; sy = a.y - b.y; dx = a.x - b.x; dy = a.y + b.y;
+            wqx = (R) 0.5 * w.y; wqy = (R) 0.5 * w.x;
+            wdx = dx * wqx - dy * wqy; wdy = dx * wqy + dy * wqx;
+            up[T * i] = (R) 0.5 * sx + wdx;                                             // Re Z'[k]
+            dn[T * (15 - i)] = (R) 0.5 * sx - wdx;                                      // Re Z'[L-k]
+            zky[i] = (R) 0.5 * sy + wdy;
+            zmy[i] = wdy - (R) 0.5 * sy;
+        }
+        if (t == 0) {                                                         // k = L/2: X = conj Z, then Z' = conj(X H); after the loop: its
+            const R ay = stage[L / 2];                                        // slot is nobody's pair (T * 16 = L/2 belongs to i = 16)
+            const C ym = cmul(C{amx, -ay}, buf_load<kCached>(rh, (L / 2) * CB, 0, R{}));
+            zmid = C{ym.x, -ym.y};
+            stage[L / 2] = zmid.x;
+        }
+        lds_barrier();
+        // ---- back to the load layout of the inverse transform: v[j1] = Z'[T j1 + t]
+    #pragma unroll
+        for (int j1 = 0; j1 < 32; ++j1) v[j1].x = up[T * j1];
+        lds_barrier();
+    #pragma unroll
+        for (int i = 0; i < 16; ++i) { up[T * i] = zky[i]; dn[T * (15 - i)] = zmy[i]; }
+        if (t == 0) stage[L / 2] = zmid.y;
+        lds_barrier();
+    #pragma unroll
+        for (int j1 = 0; j1 < 32; ++j1) v[j1].y = up[T * j1];
+        lds_barrier();
+
     }
-    if (t == 0) {                                                         // k = L/2: X = conj Z, then Z' = conj(X H); after the loop: its
-        const R ay = stage[L / 2];                                        // slot is nobody's pair (T * 16 = L/2 belongs to i = 16)
-        const C ym = cmul(C{amx, -ay}, buf_load<kCached>(rh, (L / 2) * CB, 0, R{}));
-        zmid = C{ym.x, -ym.y};
-        stage[L / 2] = zmid.x;
-    }
-    lds_barrier();
-    // ---- back to the load layout of the inverse transform: v[j1] = Z'[T j1 + t]
-#pragma unroll
-    for (int j1 = 0; j1 < 32; ++j1) v[j1].x = up[T * j1];
-    lds_barrier();
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { up[T * i] = zky[i]; dn[T * (15 - i)] = zmy[i]; }
-    if (t == 0) stage[L / 2] = zmid.y;
-    lds_barrier();
-#pragma unroll
-    for (int j1 = 0; j1 < 32; ++j1) v[j1].y = up[T * j1];
-    lds_barrier();
 
     // an opaque copy of the table pointer: otherwise the 62 twiddles the forward passes read from the table are kept in
     // registers for the inverse passes (common subexpressions) and the kernel needs 220 VGPRs
