@@ -316,13 +316,23 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
     // N = 32768 0.885 -> 0.799 ms, 60.7 -> 67.2 % of the roofline).  The shorter f32 lines had nothing to lose (1 - 2 % slower with it,
     // tools/bench_mid.py on one box) and the f64 forms spill MORE with it (0 - 31 -> 31 - 51: hipcc starts all sixteen pairs at once);
     // both keep the two-exchange form.
+#ifdef DSC_MID_NO_PAIR_ONCE
+    constexpr bool PAIR_ONCE = false;
+#else
     constexpr bool PAIR_ONCE = sizeof(R) == 4 && !TWO && B == 16;
+#endif
+#ifdef DSC_MID_OLD_PRE
+    constexpr bool PRE_ONCE = false;
+#else
+    constexpr bool PRE_ONCE = true;                  // the inverse pre-pass that moves only the upper halves (see there)
+#endif
 #ifdef DSC_MID_OLD_POST
     constexpr bool POST_ONCE = false;
 #else
     // measured (tools/r03_call_o.sh): f32 + 0 - 1.7 points at every three-pass length; f64 lines of 2048 - 8192 points lose 1 - 2 points
     // with it (they keep the two-exchange form), the persistent f64 lines of 16384 points need its registers (49 -> 55 %)
-    constexpr bool POST_ONCE = !TWO && (sizeof(R) == 4 || B == 16);
+    // two-pass lines (the same ownership: COLS = T CPT there too): f32 + 0.3 - 0.6 points, f64 no gain (tools/r03_call_r.sh)
+    constexpr bool POST_ONCE = TWO ? (sizeof(R) == 4 && B > 1) : (sizeof(R) == 4 || B == 16);
 #endif
     if constexpr (MODE != DSC_MODE_C2R_PACKED || !PAIR_ONCE) {
 #pragma unroll
@@ -340,7 +350,44 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
         vin = g * pitch_b + t * IB;
         vout = (g * out_pitch + t) * CB;
     }
-    if constexpr (MODE == DSC_MODE_C2R_PACKED && !PAIR_ONCE) {
+    if constexpr (MODE == DSC_MODE_C2R_PACKED && !PAIR_ONCE && PRE_ONCE) {
+        // Inverse packed-real pre-pass (dsc_fft.h:194-228) with the ownership the forward post-pass uses: the thread loaded bins t + T j,
+        // its lower sixteen k and sixteen upper ones, and the partners L - k of its lower bins are upper bins of thread T - t.  The upper
+        // halves go to the staging plane (slot of bin b: b - L/2; x plane [0, L/2), y plane [L/2, L)), one barrier, then per pair
+        //   a = Y[k], b = Y[L-k], s = a + conj b, d = a - conj b, wq = (i/2) conj(W_2L^k):  Z[k] = s/2 + wq d (kept),  Z[L-k] = conj(s/2 - wq d)
+        // and Z[L-k] goes back into the slot b came from (this thread is its only reader: no barrier); second barrier, everybody collects
+        // its upper half.  Against "everybody computes its own 32 bins from two exchanged planes": half the arithmetic, no second
+        // 32-value array, two barriers instead of three.
+        const C wbase = tw_real[t];
+        C yl = C{(R) 0, (R) 0};
+        if (t == 0) { yl = load_elem(L); v[0].y = (R) 0; yl.y = (R) 0; }   // dsc_fft.h:227-228: real parts only at k = 0, L
+        R *own_x = stage + t, *own_y = stage + L / 2 + t;                 // [T (j - 16)]: slot of the own upper bin t + T j
+        R *par_x = stage + (L / 2 - 15 * T) - t;                          // [T (15 - j)]: slot of L - k, k = t + T j
+        R *par_y = par_x + L / 2;
+#pragma unroll
+        for (int j = 16; j < 32; ++j) { own_x[T * (j - 16)] = v[j].x; own_y[T * (j - 16)] = v[j].y; }
+        if (t == 0) own_y[0] = -v[16].y;                                  // bin L/2 pairs with itself: Z[L/2] = conj Y[L/2], nobody's partner
+        lds_barrier();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const C a = v[j];
+            C b = C{par_x[T * (15 - j)], par_y[T * (15 - j)]};
+            if (j == 0 && t == 0) b = yl;                                 // Y[L] (the slot read is somebody else's: ignored)
+            const C w = cmul(wbase, C{(R) root64_re(j), (R) root64_im(j)});      // W_2L^{t + T j} = W_2L^t W_64^j
+            const R wqx = (R) 0.5 * w.y, wqy = (R) 0.5 * w.x;
+            const R sx = (R) 0.5 * (a.x + b.x), sy = (R) 0.5 * (a.y - b.y), dx = a.x - b.x, dy = a.y + b.y;
+            const R wdx = dx * wqx - dy * wqy, wdy = dx * wqy + dy * wqx;
+            v[j] = C{sx + wdx, sy + wdy};
+            if (!(j == 0 && t == 0)) {                                    // Z[L] is no bin
+                par_x[T * (15 - j)] = sx - wdx;
+                par_y[T * (15 - j)] = wdy - sy;
+            }
+        }
+        lds_barrier();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[16 + j] = C{own_x[T * j], own_y[T * j]};
+    }
+    if constexpr (MODE == DSC_MODE_C2R_PACKED && !PAIR_ONCE && !PRE_ONCE) {
         // Z[k] = (a + conj b)/2 + wq (a - conj b), a = Y[k], b = Y[L-k], wq = (i/2) conj(W_2L^k), for the
         // thread's own k = T j1 + t; b comes through the staging plane, one component at a time.
         const C wbase = tw_real[t];
@@ -595,7 +642,9 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO, 1>::NT), (mid_cfg<R, B, TWO, 1>
 #ifdef DSC_MID_OLD_FILTER_PAIRS
     constexpr bool ONCE = false;
 #else
-    constexpr bool ONCE = !TWO;
+    // two-pass lines, measured (tools/r03_call_r.sh): f32 N = 512 / 1024 / 2048: 48.6 -> 50.2, 50.2 -> 54.1, 44.9 -> 49.3 %; f64 N = 512
+    // 57.7 -> 60.1 %, but N = 1024 and 2048 LOSE with it (59.7 -> 49.1, 56.8 -> 50.6 %: the second 32-value array costs their occupancy)
+    constexpr bool ONCE = !TWO || sizeof(R) == 4 || B == 8;
 #endif
     if constexpr (ONCE) {
         // ---- three-pass lines, round 3.  The column layout leaves thread t with the bins t + T m, m = 0 .. 31: its sixteen lower bins k
