@@ -312,19 +312,14 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
     for (int i = tid; i < cfg::TABLE; i += NT) wtab[i] = tw_full[(long long) i * cfg::TABLE_STRIDE];    // W_1024^m = W_L^{B m}
 
     C v[32];
-    // The pair-once inverse pre-pass below where it removes spills: the f32 lines of 16384 points (11 spilled registers -> 4; irfft
-    // N = 32768 0.885 -> 0.799 ms, 60.7 -> 67.2 % of the roofline).  The shorter f32 lines had nothing to lose (1 - 2 % slower with it,
-    // tools/bench_mid.py on one box) and the f64 forms spill MORE with it (0 - 31 -> 31 - 51: hipcc starts all sixteen pairs at once);
-    // both keep the two-exchange form.
-#ifdef DSC_MID_NO_PAIR_ONCE
-    constexpr bool PAIR_ONCE = false;
-#else
-    constexpr bool PAIR_ONCE = sizeof(R) == 4 && !TWO && B == 16;
-#endif
 #ifdef DSC_MID_OLD_PRE
     constexpr bool PRE_ONCE = false;
 #else
-    constexpr bool PRE_ONCE = true;                  // the inverse pre-pass that moves only the upper halves (see there)
+    // the inverse pre-pass that moves only the upper halves (see there).  Measured against the two-exchange form (tools/r03_call_s.sh):
+    // f32 lines of 16384 points 67.5 -> 70.4 % (it replaced a form that loaded the partners from memory, 4 spilled registers), the
+    // persistent f64 lines of 16384 points 52.3 -> 55.0 % (43 spilled registers -> 0), everything else within +- 0.8 points; the two
+    // f64 forms that measured 0.7 - 1 point lower with it (lines of 1024 and 2048 points) keep the two-exchange form.
+    constexpr bool PRE_ONCE = !(sizeof(R) == 8 && ((TWO && B == 32) || (!TWO && B == 2)));
 #endif
 #ifdef DSC_MID_OLD_POST
     constexpr bool POST_ONCE = false;
@@ -334,11 +329,10 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
     // two-pass lines (the same ownership: COLS = T CPT there too): f32 + 0.3 - 0.6 points, f64 no gain (tools/r03_call_r.sh)
     constexpr bool POST_ONCE = TWO ? (sizeof(R) == 4 && B > 1) : (sizeof(R) == 4 || B == 16);
 #endif
-    if constexpr (MODE != DSC_MODE_C2R_PACKED || !PAIR_ONCE) {
+    {
 #pragma unroll
         for (int j1 = 0; j1 < 32; ++j1) v[j1] = load_elem(T * j1);                           // z[T j1 + t]
     }
-    static_assert(!(PIPE && PAIR_ONCE), "the persistent form requests the whole next line into v");
     do {
     const long long next_line = line0 + (long long) gridDim.x;
     const bool more = PIPE && next_line < n_lines;                  // uniform
@@ -350,7 +344,7 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
         vin = g * pitch_b + t * IB;
         vout = (g * out_pitch + t) * CB;
     }
-    if constexpr (MODE == DSC_MODE_C2R_PACKED && !PAIR_ONCE && PRE_ONCE) {
+    if constexpr (MODE == DSC_MODE_C2R_PACKED && PRE_ONCE) {
         // Inverse packed-real pre-pass (dsc_fft.h:194-228) with the ownership the forward post-pass uses: the thread loaded bins t + T j,
         // its lower sixteen k and sixteen upper ones, and the partners L - k of its lower bins are upper bins of thread T - t.  The upper
         // halves go to the staging plane (slot of bin b: b - L/2; x plane [0, L/2), y plane [L/2, L)), one barrier, then per pair
@@ -387,7 +381,7 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[16 + j] = C{own_x[T * j], own_y[T * j]};
     }
-    if constexpr (MODE == DSC_MODE_C2R_PACKED && !PAIR_ONCE && !PRE_ONCE) {
+    if constexpr (MODE == DSC_MODE_C2R_PACKED && !PRE_ONCE) {
         // Z[k] = (a + conj b)/2 + wq (a - conj b), a = Y[k], b = Y[L-k], wq = (i/2) conj(W_2L^k), for the
         // thread's own k = T j1 + t; b comes through the staging plane, one component at a time.
         const C wbase = tw_real[t];
@@ -421,50 +415,6 @@ __global__ __launch_bounds__((mid_cfg<R, B, TWO>::NT), (mid_cfg<R, B, TWO>::WAVE
             const R zy = (R) 0.5 * sy + (dx[j1] * wqy + dy * wqx);
             v[j1] = C{zx, zy};
         }
-    }
-    if constexpr (MODE == DSC_MODE_C2R_PACKED && PAIR_ONCE) {
-        // Inverse packed-real pre-pass (dsc_fft.h:194-228), every pair (k, L - k) ONCE (round 3): the thread loads its lower sixteen bins
-        // k = T j + t AND their partners Y[L - k] (descending addresses across the lanes: the same coalesced pieces as its own upper half),
-        // computes  s = a + conj b, d = a - conj b, wq = (i/2) conj(W_2L^k):  Z[k] = s/2 + wq d  (kept),  Z[L - k] = conj(s/2 - wq d)
-        // and hands Z[L - k] to its owner through the staging plane — half the arithmetic of "everybody computes its own 32 bins", one
-        // exchange instead of two and no second 32-value array (that form spilled 2 - 38 registers).
-        const C wbase = tw_real[t];                                 // requested first: the pairs wait for it
-        constexpr int kOut = 0x7f000000;
-        const int vin_m = g * pitch_b + ((L - 15 * T) - t) * CB;    // element L - T j - t = (L - 15 T - t) + T (15 - j)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            v[j] = load_elem(T * j);
-            v[16 + j] = buf_load<LOADP>(rin, (!PAD || ((L - 15 * T) - t + T * (15 - j)) * CB < in_len_b) ? vin_m : kOut, T * (15 - j) * CB, R{});
-        }
-        C ymid = C{(R) 0, (R) 0};
-        if (t == 0) { ymid = load_elem(L / 2); v[0].y = (R) 0; v[16].y = (R) 0; }   // bin L/2 pairs with itself; bins 0 and L: real parts only (dsc_fft.h:227-228)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const C w = cmul(wbase, C{(R) root64_re(j), (R) root64_im(j)});        // W_2L^{t + T j} = W_2L^t W_64^j
-            const R wqx = (R) 0.5 * w.y, wqy = (R) 0.5 * w.x;
-            const C a = v[j], b = v[16 + j];
-            const R sx = (R) 0.5 * (a.x + b.x), sy = (R) 0.5 * (a.y - b.y), dx = a.x - b.x, dy = a.y + b.y;
-            const R wdx = dx * wqx - dy * wqy, wdy = dx * wqy + dy * wqx;
-            v[j] = C{sx + wdx, sy + wdy};
-            v[16 + j] = C{sx - wdx, wdy - sy};
-        }
-        // Z[L - k] goes to staging index L - k; everybody then reads its own upper half T j' + t, j' = 16 .. 31.  Thread 0 pairs with itself
-        // (its Z[L - T j] are its own rows 32 - j) and supplies Z[L/2] = conj Y[L/2]; its write at index L is never read.
-        R *up = stage + (L - 15 * T) - t;           // up[T (15 - j)] = stage[L - k]
-        const R *dn = stage + 16 * T + t;           // dn[T j]        = stage[T (16 + j) + t]
-#pragma unroll
-        for (int j = 0; j < 16; ++j) up[T * (15 - j)] = v[16 + j].x;
-        if (t == 0) stage[L / 2] = ymid.x;
-        lds_barrier();
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[16 + j].x = dn[T * j];
-        lds_barrier();
-#pragma unroll
-        for (int j = 0; j < 16; ++j) up[T * (15 - j)] = v[16 + j].y;
-        if (t == 0) stage[L / 2] = -ymid.y;
-        lds_barrier();
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[16 + j].y = dn[T * j];
     }
     __syncthreads();                // twiddle table visible; staging reads done before the plane is reused
 
