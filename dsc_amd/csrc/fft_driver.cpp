@@ -270,6 +270,33 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
         }
     }
 
+    // Long complex transforms along a non-last axis (dsc_fft / dsc_ifft, complex or real input, full lines): four-step in two passes of
+    // the column kernel — two streaming passes with whole tile rows instead of the three of the transpose route below.  One full-size
+    // temporary in the main arena.  (DSC_COLS_4STEP_MIN: smallest length that takes this route; 0 switches it off.)
+    {
+        static const long long min_4step = [] { const char *e = getenv("DSC_COLS_4STEP_MIN"); return e ? atoll(e) : 4096LL; }();
+        const int x_n = j.x->shape[j.slot], out_n = j.out->shape[j.slot];
+        int n1 = 0, n2 = 0;
+        if (inner >= 8 && min_4step > 0 && j.L >= min_4step && (j.mode == DSC_MODE_C2C || j.mode == DSC_MODE_R2C_CAST) && x_n == j.L && j.in_len == j.L &&
+            out_n == j.L && j.L <= (1 << 22) && dsc_fft_cols_4step_split(j.L, sp, &n1, &n2)) {
+            const size_t csz = dsc_dtype_size(j.out->dtype);
+            const size_t slice_bytes = (size_t) j.L * inner * csz;                     // pass 1 addresses a whole [n][inner] slice with 32-bit offsets
+            const size_t work_bytes = (size_t) j.out->ne * csz;
+            if (slice_bytes < 0x7f000000u && (long long) n1 * inner < (1LL << 30) && (n_lines / inner) * n2 < (1LL << 31) && ctx->main.fits(work_bytes, 0)) {
+                const dsc_dtype cdt = j.out->dtype;
+                const dsc_fft_plan *p1 = dsc_plan_fft(ctx, n1, DSC_FFT_COMPLEX, cdt);
+                const dsc_fft_plan *p2 = dsc_plan_fft(ctx, n2, DSC_FFT_COMPLEX, cdt);
+                const dsc_fft_plan *pn = dsc_plan_fft(ctx, j.L, DSC_FFT_COMPLEX, cdt);
+                dsc_tensor *work = dsc_new_tensor(ctx, j.out->n_dim, &j.out->shape[DSC_MAX_DIMS - j.out->n_dim], cdt, nullptr);
+                dsc_launch_fft_cols_4step(j.x->data, work->data, j.out->data, n_lines / inner, (int) inner, n1, n2, j.mode, j.inverse, sp, p1->tw_full,
+                                          p2->tw_full, pn->tw_full, j.scale, ctx->stream);
+                dsc_tensor_free(ctx, work);              // stream ordered: whoever reuses the block is enqueued after these launches
+                ctx->last_fft_path = "cols_4step";
+                return;
+            }
+        }
+    }
+
     // Strided lines (a transform along a non-last axis) of a length the register kernels cover: transpose the axis to the
     // back (32 x 32 LDS tiles), transform contiguous rows, transpose the result back — three streaming passes instead of
     // one latency-bound strided pass (measured 1.3-4x faster from 512 points up; below that the strided LDS kernel wins).

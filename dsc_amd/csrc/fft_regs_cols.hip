@@ -32,6 +32,18 @@ __device__ __forceinline__ void store_real(double a, __amdgpu_buffer_rsrc_t r, i
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, a), r, voff, soff, kStream);
 }
 
+// The two halves of a four-step transform along an axis of n = n1 n2 points (tensor [S][n][C], dsc_launch_fft_cols_4step below) are this
+// kernel with two additions on the complex modes' way out:
+//   tw4 / tw4_div   pass 1 (view [S][n2][n1 C], lines over j2): bin k2 of column q is multiplied by W_n^{j1 k2}, j1 = q / tw4_div
+//   out_pitch/group pass 2 (view [S n2][n1][C], lines over j1): bin k1 of slice (s, k2) goes to row n2 k1 + k2 of slice s — consecutive
+//                   bins are out_pitch elements apart and slice sigma starts at (sigma / group) (out_axis out_pitch) + (sigma % group) inner
+// Plain calls pass {inner, 1, nullptr, 1}.
+struct cols_remap {
+    int out_pitch, group;
+    const void *tw4;
+    int tw4_div;
+};
+
 template<typename R, int B, bool TWO, int CW> struct cols_cfg {
     static constexpr int T = TWO ? B : 32 * B;         // threads per column
     static constexpr int L = 32 * T;                   // complex length
@@ -140,7 +152,7 @@ __device__ __forceinline__ void cols_passes(cpx<R> (&v)[32], R *plane, const cpx
 template<typename R, int B, bool TWO, int CW, int MODE, bool INV>
 __global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO, CW>::WAVES_PER_EU)) void fft_cols_kernel(
     const void *__restrict__ in, void *__restrict__ out, int inner, int tiles_per_slice, int n_tiles, int in_axis, int in_len, int out_axis,
-    const cpx<R> *__restrict__ tw_full, const cpx<R> *__restrict__ tw_real, R scale) {
+    const cpx<R> *__restrict__ tw_full, const cpx<R> *__restrict__ tw_real, R scale, cols_remap rm) {
     using C = cpx<R>;
     using cfg = cols_cfg<R, B, TWO, CW>;
     constexpr int T = cfg::T, L = cfg::L, NT = cfg::NT, CPT = cfg::CPT, COLS = cfg::COLS, LOGB = ilog2(B);
@@ -237,8 +249,10 @@ __global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO,
     do {                                                            // one tile unless PIPE
         const int next = PIPE ? tile + (int) gridDim.x : n_tiles;
         const int slice = tile / tiles_per_slice;
+        // (plain calls: group = 1, out_pitch = inner — slice * out_axis * inner elements, a range of out_axis * inner)
+        const size_t out_base = (size_t) (slice / rm.group) * out_axis * rm.out_pitch + (size_t) (slice % rm.group) * inner;
         const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
-            (void *) ((char *) out + (size_t) slice * out_axis * inner * OB), 0, out_axis * inner * OB, 0x00020000);
+            (void *) ((char *) out + out_base * OB), 0, ((out_axis - 1) * rm.out_pitch + inner) * OB, 0x00020000);
 
         if constexpr (MODE == DSC_MODE_C2R_PACKED && !PAIR_ONCE && T == 1) {
             // 32-point lines, one thread per column: both partners of every pair live in this thread — no staging, no barrier.
@@ -341,8 +355,18 @@ __global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO,
         R *stage = plane + c;                                       // stage[k * CW] = component of bin k of this column
 
         if constexpr (MODE == DSC_MODE_C2C || MODE == DSC_MODE_R2C_CAST) {
-            const int voff = live ? (t * inner + col) * CB : kOut;
-            const int step = inner * CB;
+            const int voff = live ? (t * rm.out_pitch + col) * CB : kOut;
+            const int step = rm.out_pitch * CB;
+            if (rm.tw4 != nullptr) {                                // four-step, pass 1: times W_n^{j1 k}, k the bin, j1 = col / tw4_div
+                const C *tw4 = (const C *) rm.tw4;
+                const int j1 = col / rm.tw4_div;
+#pragma unroll
+                for (int q = 0; q < 32; ++q) {
+                    const int k = t + T * (q / B) + COLS * brev(q % B, LOGB);
+                    const C w = tw4[live ? j1 * k : 0];
+                    v[q] = INV ? cmulc(v[q], w) : cmul(v[q], w);
+                }
+            }
             auto put = [&](int q) {                                 // q = i B + p
                 const C r = v[q];
                 buf_store<kStream>(C{r.x * scale, r.y * scale}, rout, voff, (T * (q / B) + COLS * brev(q % B, LOGB)) * step);
@@ -460,7 +484,7 @@ __global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO,
 #endif
 template<typename R, int B, bool TWO, int CW, int MODE, bool INV>
 void launch_cols_one(const void *in, void *out, long long slices, int inner, int in_axis, int in_len, int out_axis, const void *tw_full,
-                     const void *tw_real, double scale, hipStream_t stream) {
+                     const void *tw_real, double scale, const cols_remap &rm, hipStream_t stream) {
     using cfg = cols_cfg<R, B, TWO, CW>;
     constexpr size_t lds = cols_lds_bytes<R, B, TWO, CW>();
     static unsigned long long attr_devices = 0;
@@ -479,18 +503,18 @@ void launch_cols_one(const void *in, void *out, long long slices, int inner, int
         if (grid > cus[dev]) grid = cus[dev];
     }
     DSC_LAUNCH((fft_cols_kernel<R, B, TWO, CW, MODE, INV>), dim3((unsigned) grid), dim3(cfg::NT), lds, stream, in, out, inner, tiles, (int) n_tiles,
-               in_axis, in_len, out_axis, (const cpx<R> *) tw_full, (const cpx<R> *) tw_real, (R) scale);
+               in_axis, in_len, out_axis, (const cpx<R> *) tw_full, (const cpx<R> *) tw_real, (R) scale, rm);
 }
 
 template<typename R, int B, bool TWO, int CW>
 void launch_cols_mode(dsc_fft_mode mode, bool inverse, const void *in, void *out, long long slices, int inner, int in_axis, int in_len, int out_axis,
-                      const void *tw_full, const void *tw_real, double scale, hipStream_t stream) {
-    if (mode == DSC_MODE_R2C_PACKED)      launch_cols_one<R, B, TWO, CW, DSC_MODE_R2C_PACKED, false>(in, out, slices, inner, in_axis, in_len, out_axis, tw_full, tw_real, scale, stream);
-    else if (mode == DSC_MODE_C2R_PACKED) launch_cols_one<R, B, TWO, CW, DSC_MODE_C2R_PACKED, true>(in, out, slices, inner, in_axis, in_len, out_axis, tw_full, tw_real, scale, stream);
-    else if (mode == DSC_MODE_R2C_CAST && inverse) launch_cols_one<R, B, TWO, CW, DSC_MODE_R2C_CAST, true>(in, out, slices, inner, in_axis, in_len, out_axis, tw_full, tw_real, scale, stream);
-    else if (mode == DSC_MODE_R2C_CAST)   launch_cols_one<R, B, TWO, CW, DSC_MODE_R2C_CAST, false>(in, out, slices, inner, in_axis, in_len, out_axis, tw_full, tw_real, scale, stream);
-    else if (inverse)                     launch_cols_one<R, B, TWO, CW, DSC_MODE_C2C, true>(in, out, slices, inner, in_axis, in_len, out_axis, tw_full, tw_real, scale, stream);
-    else                                  launch_cols_one<R, B, TWO, CW, DSC_MODE_C2C, false>(in, out, slices, inner, in_axis, in_len, out_axis, tw_full, tw_real, scale, stream);
+                      const void *tw_full, const void *tw_real, double scale, const cols_remap &rm, hipStream_t stream) {
+    if (mode == DSC_MODE_R2C_PACKED)      launch_cols_one<R, B, TWO, CW, DSC_MODE_R2C_PACKED, false>(in, out, slices, inner, in_axis, in_len, out_axis, tw_full, tw_real, scale, rm, stream);
+    else if (mode == DSC_MODE_C2R_PACKED) launch_cols_one<R, B, TWO, CW, DSC_MODE_C2R_PACKED, true>(in, out, slices, inner, in_axis, in_len, out_axis, tw_full, tw_real, scale, rm, stream);
+    else if (mode == DSC_MODE_R2C_CAST && inverse) launch_cols_one<R, B, TWO, CW, DSC_MODE_R2C_CAST, true>(in, out, slices, inner, in_axis, in_len, out_axis, tw_full, tw_real, scale, rm, stream);
+    else if (mode == DSC_MODE_R2C_CAST)   launch_cols_one<R, B, TWO, CW, DSC_MODE_R2C_CAST, false>(in, out, slices, inner, in_axis, in_len, out_axis, tw_full, tw_real, scale, rm, stream);
+    else if (inverse)                     launch_cols_one<R, B, TWO, CW, DSC_MODE_C2C, true>(in, out, slices, inner, in_axis, in_len, out_axis, tw_full, tw_real, scale, rm, stream);
+    else                                  launch_cols_one<R, B, TWO, CW, DSC_MODE_C2C, false>(in, out, slices, inner, in_axis, in_len, out_axis, tw_full, tw_real, scale, rm, stream);
 }
 
 }  // namespace
@@ -505,10 +529,11 @@ bool dsc_fft_regs_cols_supports(int L, dsc_fft_mode mode, bool single_precision)
 // Tensor [slices][axis][inner] (contiguous), transform along `axis`: in has in_axis elements along it of which in_len are
 // used (the rest of the transform length is zero), out has out_axis.  Element counts are in each side's own element type
 // (reals on the real side of the packed modes).  Every slice must stay below 2 GiB (32-bit buffer offsets): the caller checks.
-void dsc_launch_fft_regs_cols(const void *in, void *out, long long slices, int inner, int L, dsc_fft_mode mode, bool inverse, bool single_precision,
-                              const void *tw_full, const void *tw_real, double scale, int in_axis, int in_len, int out_axis, hipStream_t stream) {
+static void launch_cols_len(const void *in, void *out, long long slices, int inner, int L, dsc_fft_mode mode, bool inverse, bool single_precision,
+                            const void *tw_full, const void *tw_real, double scale, int in_axis, int in_len, int out_axis, const cols_remap &rm,
+                            hipStream_t stream) {
     if (slices <= 0 || inner <= 0) return;
-#define COLS_ARGS mode, inverse, in, out, slices, inner, in_axis, in_len, out_axis, tw_full, tw_real, scale, stream
+#define COLS_ARGS mode, inverse, in, out, slices, inner, in_axis, in_len, out_axis, tw_full, tw_real, scale, rm, stream
     if (single_precision) {
         switch (L) {
             case 32:   launch_cols_mode<float, 1, true, 256>(COLS_ARGS); break;
@@ -535,4 +560,39 @@ void dsc_launch_fft_regs_cols(const void *in, void *out, long long slices, int i
         }
     }
 #undef COLS_ARGS
+}
+
+void dsc_launch_fft_regs_cols(const void *in, void *out, long long slices, int inner, int L, dsc_fft_mode mode, bool inverse, bool single_precision,
+                              const void *tw_full, const void *tw_real, double scale, int in_axis, int in_len, int out_axis, hipStream_t stream) {
+    launch_cols_len(in, out, slices, inner, L, mode, inverse, single_precision, tw_full, tw_real, scale, in_axis, in_len, out_axis,
+                    cols_remap{inner, 1, nullptr, 1}, stream);
+}
+
+// Complex transform of n = n1 n2 points along the middle axis of a contiguous [slices][n][inner] tensor (dsc_fft / dsc_ifft along a
+// non-last axis, dsc.cpp:1977-1978 + the strided iterator, for lengths beyond the one-pass column kernel) as a four-step transform in
+// TWO passes of the column kernel over HBM, j = j1 + n1 j2, k = n2 k1 + k2:
+//   pass 1   view [slices][n2][n1 inner], lines over j2 (n2 points, n1 inner apart), times W_n^{j1 k2}           -> work [slices][k2][j1][inner]
+//   pass 2   view [slices n2][n1][inner], lines over j1 (n1 points), bin k1 of slice (s, k2) to row n2 k1 + k2   -> out
+// Both passes move pieces of a whole tile row (32 - 128 columns); the route through two transposes and a row transform is three
+// passes.  mode: DSC_MODE_C2C or DSC_MODE_R2C_CAST (real input, widened while pass 1 loads).  work: slices n inner complex.
+// tw1 / tw2: W_{n1}^m / W_{n2}^m (the complex plans of the two lengths), twn: W_n^m, m < n.  The caller checks the 2 GiB slice limit.
+bool dsc_fft_cols_4step_split(int n, bool single_precision, int *n1, int *n2) {
+    int lg = 0;
+    while ((1 << lg) < n) ++lg;
+    if ((1 << lg) != n || lg < 10) return false;
+    const int a = 1 << (lg / 2), b = n / a;                 // a <= b; the longer lines go to pass 1, whose tiles are always whole
+    if (a < 32 || b > (single_precision ? 2048 : 2048)) return false;
+    *n1 = a;
+    *n2 = b;
+    return true;
+}
+
+void dsc_launch_fft_cols_4step(const void *in, void *work, void *out, long long slices, int inner, int n1, int n2, dsc_fft_mode mode, bool inverse,
+                               bool single_precision, const void *tw1, const void *tw2, const void *twn, double scale, hipStream_t stream) {
+    const int n = n1 * n2;
+    launch_cols_len(in, work, slices, n1 * inner, n2, mode, inverse, single_precision, tw2, nullptr, 1.0, n2, n2, n2,
+                    cols_remap{n1 * inner, 1, twn, inner}, stream);
+    launch_cols_len(work, out, slices * n2, inner, n1, DSC_MODE_C2C, inverse, single_precision, tw1, nullptr, scale, n1, n1, n1,
+                    cols_remap{n2 * inner, n2, nullptr, 1}, stream);
+    (void) n;
 }

@@ -111,6 +111,10 @@ void   dsc_launch_filter64k(const float *s, const void *H, float *y, int batch, 
 bool   dsc_fft_regs_cols_supports(int L, dsc_fft_mode mode, bool single_precision);
 void   dsc_launch_fft_regs_cols(const void *in, void *out, long long slices, int inner, int L, dsc_fft_mode mode, bool inverse, bool single_precision,
                                 const void *tw_full, const void *tw_real, double scale, int in_axis, int in_len, int out_axis, hipStream_t stream);
+// complex transform of n = n1 n2 points along the middle axis of [slices][n][inner] in two passes of the column kernel (four-step)
+bool   dsc_fft_cols_4step_split(int n, bool single_precision, int *n1, int *n2);
+void   dsc_launch_fft_cols_4step(const void *in, void *work, void *out, long long slices, int inner, int n1, int n2, dsc_fft_mode mode, bool inverse,
+                                 bool single_precision, const void *tw1, const void *tw2, const void *twn, double scale, hipStream_t stream);
 
 // ---- long real transforms in two passes over HBM (fft_r2c_2pass.hip): packed complex length L = 32768 (f64 only),
 // 65536 ... 1048576; f32 and f64.  forward: reals -> out = [rows][L + 1] bins; inverse: bins -> [rows][2L] reals.
