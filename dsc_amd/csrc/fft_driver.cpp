@@ -247,31 +247,9 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
     lines_of(j.x, j.slot, &n_lines, &inner, &lin);
     lines_of(j.out, j.slot, &n_lines, &inner, &lout);
 
-    // Strided lines of complex length 32 .. 2048 (4096): the column kernel (lanes = neighbouring lines), one pass over HBM.
-    static const bool cols_off = getenv("DSC_NO_COLS") != nullptr;            // A/B aid (tools/bench_axis0.py)
-    const bool tiny_cols = dsc_fft_tiny_supports(j.L) && getenv("DSC_NO_TINY") == nullptr;
-    if (inner > 1 && !cols_off && inner < (1LL << 30) && (tiny_cols || dsc_fft_regs_cols_supports(j.L, j.mode, sp))) {
-        const int x_n = j.x->shape[j.slot], out_n = j.out->shape[j.slot];
-        const size_t in_slice = (size_t) x_n * inner * dsc_dtype_size(j.x->dtype), out_slice = (size_t) out_n * inner * dsc_dtype_size(j.out->dtype);
-        // largest offsets the kernel forms: over the transform length, not the axis length (zero padding reads past a short axis)
-        const size_t rows_in = j.mode == DSC_MODE_R2C_PACKED ? 2 * (size_t) j.L : j.mode == DSC_MODE_C2R_PACKED ? (size_t) j.L + 1 : (size_t) j.L;
-        const size_t span = rows_in * inner * dsc_dtype_size(j.x->dtype);
-        if (in_slice < 0x7f000000u && out_slice < 0x7f000000u && span < 0x7f000000u) {     // 32-bit buffer offsets
-            if (tiny_cols) {
-                dsc_launch_fft_tiny_cols(j.x->data, j.out->data, n_lines / inner, (int) inner, j.L, j.mode, j.inverse, sp, j.scale, x_n,
-                                         j.in_len < x_n ? j.in_len : x_n, out_n, ctx->stream);
-                ctx->last_fft_path = "regs_tiny_cols";
-                return;
-            }
-            dsc_launch_fft_regs_cols(j.x->data, j.out->data, n_lines / inner, (int) inner, j.L, j.mode, j.inverse, sp, plan->tw_full, plan->tw_real,
-                                     j.scale, x_n, j.in_len < x_n ? j.in_len : x_n, out_n, ctx->stream);
-            ctx->last_fft_path = "regs_cols";
-            return;
-        }
-    }
-
     // Long complex transforms along a non-last axis (dsc_fft / dsc_ifft, complex or real input, full lines): four-step in two passes of
-    // the column kernel — two streaming passes with whole tile rows instead of the three of the transpose route below.  One full-size
+    // the column kernel — two streaming passes with whole tile rows instead of the three of the transpose route below
+    // (33 - 34 % of the roofline against 20 - 22 %; 4096-point c32 lines: against 24 % for the one-pass column kernel with its 64-B pieces).  One full-size
     // temporary in the main arena.  (DSC_COLS_4STEP_MIN: smallest length that takes this route; 0 switches it off.)
     {
         static const long long min_4step = [] { const char *e = getenv("DSC_COLS_4STEP_MIN"); return e ? atoll(e) : 4096LL; }();
@@ -294,6 +272,29 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
                 ctx->last_fft_path = "cols_4step";
                 return;
             }
+        }
+    }
+
+    // Strided lines of complex length 32 .. 2048 (4096): the column kernel (lanes = neighbouring lines), one pass over HBM.
+    static const bool cols_off = getenv("DSC_NO_COLS") != nullptr;            // A/B aid (tools/bench_axis0.py)
+    const bool tiny_cols = dsc_fft_tiny_supports(j.L) && getenv("DSC_NO_TINY") == nullptr;
+    if (inner > 1 && !cols_off && inner < (1LL << 30) && (tiny_cols || dsc_fft_regs_cols_supports(j.L, j.mode, sp))) {
+        const int x_n = j.x->shape[j.slot], out_n = j.out->shape[j.slot];
+        const size_t in_slice = (size_t) x_n * inner * dsc_dtype_size(j.x->dtype), out_slice = (size_t) out_n * inner * dsc_dtype_size(j.out->dtype);
+        // largest offsets the kernel forms: over the transform length, not the axis length (zero padding reads past a short axis)
+        const size_t rows_in = j.mode == DSC_MODE_R2C_PACKED ? 2 * (size_t) j.L : j.mode == DSC_MODE_C2R_PACKED ? (size_t) j.L + 1 : (size_t) j.L;
+        const size_t span = rows_in * inner * dsc_dtype_size(j.x->dtype);
+        if (in_slice < 0x7f000000u && out_slice < 0x7f000000u && span < 0x7f000000u) {     // 32-bit buffer offsets
+            if (tiny_cols) {
+                dsc_launch_fft_tiny_cols(j.x->data, j.out->data, n_lines / inner, (int) inner, j.L, j.mode, j.inverse, sp, j.scale, x_n,
+                                         j.in_len < x_n ? j.in_len : x_n, out_n, ctx->stream);
+                ctx->last_fft_path = "regs_tiny_cols";
+                return;
+            }
+            dsc_launch_fft_regs_cols(j.x->data, j.out->data, n_lines / inner, (int) inner, j.L, j.mode, j.inverse, sp, plan->tw_full, plan->tw_real,
+                                     j.scale, x_n, j.in_len < x_n ? j.in_len : x_n, out_n, ctx->stream);
+            ctx->last_fft_path = "regs_cols";
+            return;
         }
     }
 

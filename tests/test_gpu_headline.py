@@ -455,6 +455,35 @@ def test_mid_sizes_padded_and_cropped(dsc, dt, n):
             assert_close(b.numpy()[0], port.irfft(Y[0], bins), what=f'irfft bins={bins} ls={ls}')
 
 
+@pytest.mark.parametrize('dt', [np.complex64, np.complex128])
+def test_long_complex_transforms_along_a_non_last_axis(dsc, dt):
+    """dsc_fft / dsc_ifft along a non-last axis (dsc.cpp:1977-1978: any axis, through the strided iterator) at 4096 points and more:
+    the four-step route of the column kernel (two passes: lines over j2 with the W_n^{j1 k2} twiddle, then lines over j1 written to
+    rows n2 k1 + k2).  Complex and real input, 2-D and 3-D, inner sizes that leave the last tile ragged; every element against
+    numpy in f64 and sampled columns against the oracle; a padded call (n != axis length) must leave the route."""
+    from oracle import port
+    rng = np.random.default_rng(4)
+    tol = 1e-6 if dt == np.complex64 else 1e-14
+    for shape, axis in (((4096, 40), 0), ((8192, 33), 0), ((3, 16384, 17), 1), ((65536, 24), 0), ((2, 131072, 9), 1)):
+        z = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(dt)
+        for name in ('fft', 'ifft'):
+            got = getattr(dsc, name)(dsc.from_numpy(z), axis=axis).numpy()
+            assert dsc.last_fft_path() == 'cols_4step', (shape, name, dsc.last_fft_path())
+            want = getattr(np.fft, name)(z.astype(np.complex128), axis=axis)
+            assert rel_l2(got, want) <= tol, (shape, name)
+            assert float(np.max(np.abs(got - want)) / np.max(np.abs(want))) <= 8 * tol, (shape, name)
+            col = (slice(None), shape[1] - 1) if axis == 0 else (shape[0] - 1, slice(None), 3)
+            assert_close(got[col], getattr(port, name)(np.ascontiguousarray(z[col])), what=f'{name} {shape} one column against the oracle')
+        x = np.ascontiguousarray(z.real)
+        got = dsc.fft(dsc.from_numpy(x), axis=axis).numpy()                 # real input, widened while pass 1 loads
+        assert dsc.last_fft_path() == 'cols_4step'
+        assert rel_l2(got, np.fft.fft(x.astype(np.float64), axis=axis)) <= tol, shape
+    z = (rng.standard_normal((5000, 16)) + 1j * rng.standard_normal((5000, 16))).astype(dt)
+    got = dsc.fft(dsc.from_numpy(z), n=4096, axis=0).numpy()                 # cropped: not a full line
+    assert dsc.last_fft_path() != 'cols_4step'
+    assert rel_l2(got, np.fft.fft(z.astype(np.complex128), n=4096, axis=0)) <= tol
+
+
 def test_f64_lines_of_16384_points_more_lines_than_workgroups(dsc):
     """f64 lines of 16384 complex points run in a PERSISTENT form of fft_mid_kernel: one group per CU walks lines blockIdx.x,
     + gridDim.x, ... and requests its next line while it stores the current one.  600 lines on 256 CUs: every group walks two or

@@ -44,7 +44,7 @@ if '--bench' in sys.argv:
                 f()
             best = min(best, B.dsc_timer_stop(ctx) / reps)
         return best
-    for shape in ((4096, 32768), (8192, 16384), (16384, 8192), (65536, 2048), (262144, 512), (1048576, 128)):
+    for shape in ((2048, 65536), (4096, 32768), (8192, 16384), (16384, 8192), (65536, 2048), (262144, 512), (1048576, 128)):
         z = dsc.from_numpy((rng.standard_normal(shape) + 0j).astype(np.complex64))
         out = dsc.empty(shape, dsc.Dtype.C32)
         nb = 2 * z.ne * 8
