@@ -762,9 +762,15 @@ def test_column_kernel_every_length_and_mode(dsc, dt, L):
     # complex transform of length L along axis 1 of [2, L, inner]
     z = (rng.standard_normal((2, L, inner)) + 1j * rng.standard_normal((2, L, inner))).astype(cdt)
     Z = dsc.fft(dsc.from_numpy(z), axis=1)
-    assert (dsc.last_fft_path() == 'regs_cols') == on_cols, dsc.last_fft_path()
+    # full lines of 4096 points take the four-step route (two passes of this kernel at 64 points); the one-pass 4096-point form
+    # keeps the padded / cropped calls (below)
+    assert dsc.last_fft_path() == ('cols_4step' if L == 4096 else 'regs_cols'), dsc.last_fft_path()
     assert_close(Z.numpy(), port.fft(z, -1, 1), what=f'fft L={L}')
     assert_close(dsc.ifft(dsc.from_numpy(z), axis=1).numpy(), port.ifft(z, -1, 1), what=f'ifft L={L}')
+    zs = z[:, :L - 11]                                     # zero padded: axis shorter than the transform
+    Zp = dsc.fft(dsc.from_numpy(np.ascontiguousarray(zs)), n=L, axis=1)
+    assert (dsc.last_fft_path() == 'regs_cols') == on_cols, dsc.last_fft_path()
+    assert_close(Zp.numpy(), port.fft(zs, L, 1), what=f'fft padded L={L}')
     # real transform of 2L points along axis 0 of [2L, inner]: full, zero padded (axis shorter than n), cropped (axis longer)
     x = rng.standard_normal((2 * L, inner)).astype(dt)
     X = dsc.rfft(dsc.from_numpy(x), axis=0)
@@ -849,7 +855,8 @@ def test_short_padded_and_cropped_lines_on_the_staged_register_kernel(dsc, dt):
 @pytest.mark.parametrize('dt', [np.float32, np.float64])
 def test_fft_of_real_tensors_along_strided_axes(dsc, dt):
     """dsc_fft / dsc_ifft of a REAL tensor along a non-last axis (the cast of dsc.cpp:1984-1988 happens in the gather): the column kernel
-    widens while loading (32 .. 2048 points), longer lines go through the transposes to the last-axis kernels, which do the same."""
+    widens while loading (32 .. 2048 points); longer FULL lines take the four-step route of the same kernel (pass 1 widens), padded
+    ones go through the transposes to the last-axis kernels, which widen too."""
     from oracle import port
     rng = np.random.default_rng(77)
     for n, want in ((64, 'regs_cols'), (1024, 'regs_cols'), (8192, 'regs_mid'), (65536, 'c2c_fused_l2')):
@@ -857,7 +864,8 @@ def test_fft_of_real_tensors_along_strided_axes(dsc, dt):
         for ls in (n, n - 5):
             x = rng.standard_normal((ls, cols)).astype(dt)
             F = dsc.fft(dsc.from_numpy(x), n=n, axis=0)
-            assert dsc.last_fft_path() == want, (n, dsc.last_fft_path())
+            # full lines of 4096 points and more: the four-step route of the column kernel; padded ones keep the transposes
+            assert dsc.last_fft_path() == ('cols_4step' if n >= 8192 and ls == n else want), (n, dsc.last_fft_path())
             assert_close(F.numpy(), port.fft(x, n, 0), what=f'fft(real) axis 0 n={n} ls={ls}')
             G = dsc.ifft(dsc.from_numpy(x), n=n, axis=0)
             assert_close(G.numpy(), port.ifft(x, n, 0), what=f'ifft(real) axis 0 n={n} ls={ls}')
