@@ -275,6 +275,43 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
         }
     }
 
+    // Long REAL transforms along a non-last axis (dsc_rfft / dsc_irfft, full lines, an even number of columns): two neighbouring columns
+    // as one complex column through the same four-step, the spectra separated / merged inside its passes (fft_regs_cols.hip) — two
+    // streaming passes instead of the transpose route's three.  (DSC_COLS_4STEP_REAL_MIN: smallest real length; 0 switches it off.)
+    {
+        static const long long min_real = [] { const char *e = getenv("DSC_COLS_4STEP_REAL_MIN"); return e ? atoll(e) : 8192LL; }();
+        const int x_n = j.x->shape[j.slot], out_n = j.out->shape[j.slot];
+        const long long n = 2LL * j.L;
+        const bool full = j.mode == DSC_MODE_R2C_PACKED ? (x_n == n && j.in_len == n && out_n == j.L + 1)
+                                                        : (x_n == j.L + 1 && j.in_len == j.L + 1 && out_n == n);
+        int n1 = 0, n2 = 0;
+        if (packed && full && inner >= 16 && inner % 2 == 0 && min_real > 0 && n >= min_real && n <= (1 << 22) &&
+            dsc_fft_cols_4step_split((int) n, sp, &n1, &n2) && n1 >= 64) {
+            const dsc_dtype cdt = sp ? DSC_C32 : DSC_C64;
+            const size_t csz = dsc_dtype_size(cdt);
+            const long long slices = n_lines / inner, cc_n = inner / 2;
+            const size_t real_slice = (size_t) n * inner * (csz / 2), bins_slice = (size_t) (j.L + 1) * inner * csz;
+            const size_t work_bytes = (size_t) slices * n * cc_n * csz;
+            if (real_slice < 0x7f000000u && bins_slice < 0x7f000000u && slices * n < (1LL << 31) && slices * n2 < (1LL << 31) &&
+                (long long) n1 * cc_n < (1LL << 30) && ctx->main.fits(work_bytes, 0)) {
+                const dsc_fft_plan *p1 = dsc_plan_fft(ctx, n1, DSC_FFT_COMPLEX, cdt);
+                const dsc_fft_plan *p2 = dsc_plan_fft(ctx, n2, DSC_FFT_COMPLEX, cdt);
+                const dsc_fft_plan *pn = dsc_plan_fft(ctx, (int) n, DSC_FFT_COMPLEX, cdt);
+                const int shape_w[2] = {(int) (slices * n), (int) cc_n};
+                dsc_tensor *work = dsc_new_tensor(ctx, 2, shape_w, cdt, nullptr);
+                if (j.mode == DSC_MODE_R2C_PACKED)
+                    dsc_launch_rfft_cols_4step(j.x->data, work->data, j.out->data, slices, (int) cc_n, n1, n2, sp, p1->tw_full, p2->tw_full, pn->tw_full,
+                                               ctx->stream);
+                else                                     // j.scale = 2 / n folds the halves of the packed pre-pass (dsc_fft.h:232); here: 1 / n
+                    dsc_launch_irfft_cols_4step(j.x->data, work->data, j.out->data, slices, (int) cc_n, n1, n2, sp, p1->tw_full, p2->tw_full,
+                                                pn->tw_full, 0.5 * j.scale, ctx->stream);
+                dsc_tensor_free(ctx, work);              // stream ordered
+                ctx->last_fft_path = "cols_4step_real";
+                return;
+            }
+        }
+    }
+
     // Strided lines of complex length 32 .. 2048 (4096): the column kernel (lanes = neighbouring lines), one pass over HBM.
     static const bool cols_off = getenv("DSC_NO_COLS") != nullptr;            // A/B aid (tools/bench_axis0.py)
     const bool tiny_cols = dsc_fft_tiny_supports(j.L) && getenv("DSC_NO_TINY") == nullptr;

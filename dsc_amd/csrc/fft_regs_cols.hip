@@ -473,6 +473,168 @@ __global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO,
     } while (PIPE && (tile += (int) gridDim.x) < n_tiles);
 }
 
+// ------------------------------------------------------------------------------------------------
+// REAL transforms along an axis of n = n1 n2 >= 4096 points (dsc_rfft / dsc_irfft along a non-last axis, full lines, an even number of
+// columns): TWO neighbouring real columns are one complex column — the real tensor [S][n][C] read as complex [S][n][C/2] is
+// z = x_a + i x_b — and the complex four-step above does the work; the two spectra are separated (forward) or merged (inverse) where
+// the data passes through registers anyway.  Two passes over HBM (16 B per real sample against the algorithmic 8) instead of the
+// transpose route's three.
+//
+// forward   pass 1: the plain complex pass over j2 with the W_n^{j1 k2} twiddle (fft_cols_kernel on the complex view)
+//           pass 2: cols_real_split_kernel — lines over j1 of slice k2 give Z[n2 k1 + k2]; X_a[k] = (Z[k] + conj Z[n-k]) / 2,
+//                   X_b[k] = -i (Z[k] - conj Z[n-k]) / 2, and n - k = n2 (n1 - 1 - k1) + (n2 - k2) lies in slice n2 - k2.  A workgroup
+//                   therefore takes the slice PAIR (k2, n2 - k2), half of its columns each; the partner of the lower bin k1 of one
+//                   half is the upper bin n1 - 1 - k1 of the same column in the other half: the upper halves go through the staging
+//                   plane once (the ownership of section 4.1b across the two halves), every thread separates its sixteen lower bins
+//                   and stores (X_a[k], X_b[k]) — neighbouring columns of row k — in one access.  Slice 0 pairs with itself
+//                   (partner n1 - k1, Z[n] := Z[0]) and so does slice n2 / 2; both halves then hold the same slice and only one stores.
+// inverse   pass 1: cols_real_merge_kernel — Z[k] = Y_a[k] + i Y_b[k] for k <= n/2 and conj(Y_a[n-k]) + i conj(Y_b[n-k]) above: the
+//                   mirror is an ADDRESS (row n - k of the spectrum), no exchange at all; then the inverse pass over j2 and the
+//                   conjugate twiddle, into the work tensor
+//           pass 2: the plain complex pass over j1 with the output remap; its output rows are the real rows (x_a, x_b interleaved)
+template<typename R, int B, bool TWO, int CW>
+__global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO, CW>::WAVES_PER_EU)) void cols_real_split_kernel(
+    const cpx<R> *__restrict__ work, cpx<R> *__restrict__ out, int cc_n, int tiles_per_pair, int n2, const cpx<R> *__restrict__ tw_full) {
+    using C = cpx<R>;
+    using cfg = cols_cfg<R, B, TWO, CW>;
+    constexpr int T = cfg::T, L = cfg::L, NT = cfg::NT, CPT = cfg::CPT, LOGB = ilog2(B), H = CW / 2;
+    constexpr int CB = (int) sizeof(C);
+    constexpr int kOut = 0x7f000000;
+    static_assert(T >= 2, "a line of 32 points has its pairs inside one thread: use 64 points and more");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    R *plane = (R *) lds_raw;
+    C *wtab = (C *) (plane + cfg::PLANE);
+    for (int i = threadIdx.x; i < cfg::TABLE; i += NT) wtab[i] = tw_full[(long long) i * cfg::TABLE_STRIDE];
+
+    const int tile = blockIdx.x;
+    const int ct = tile % tiles_per_pair, pr = tile / tiles_per_pair;
+    const int n_pairs = n2 / 2 + 1;
+    const int p = pr % n_pairs, s = pr / n_pairs;
+    const int k_a = p, k_b = (n2 - p) % n2;
+    const bool self = k_a == k_b;                                   // slices 0 and n2 / 2 pair with themselves
+    const int tid = threadIdx.x, c = tid % CW, t = tid / CW, h = c / H;
+    const int col = ct * H + (c - h * H);
+    const bool live = col < cc_n;
+    const int k2 = h ? k_b : k_a;
+    const long long n = (long long) L * n2;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *) (work + (size_t) s * n * cc_n), 0, (int) (n * cc_n * CB), 0x00020000);
+    C v[32];
+    {
+        const int voff = live ? ((k2 * L + t) * cc_n + col) * CB : kOut;
+        const int step = T * cc_n * CB;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) v[j] = buf_load<kStream>(rin, voff, j * step, R{});
+    }
+    __syncthreads();
+    cols_passes<R, B, TWO, CW, false>(v, plane, wtab, tw_full, t, c);      // v[reg_of(m)] = Z[n2 (t + T m) + k2] of this column
+
+    auto reg_of = [](int m) constexpr { return (m % CPT) * B + brev(m / CPT, LOGB); };
+    R *own_x = plane + c + t * CW, *own_y = own_x + (L / 2) * CW;   // [T (m - 16) CW]: slot of the own upper bin k1 = t + T m
+#pragma unroll
+    for (int m = 16; m < 32; ++m) { own_x[T * (m - 16) * CW] = v[reg_of(m)].x; own_y[T * (m - 16) * CW] = v[reg_of(m)].y; }
+    const C zmid = v[reg_of(16)];                                   // slice 0, thread 0: Z[n/2], which pairs with itself
+    lds_barrier();
+    const int shift = p == 0 ? 0 : 1;                               // partner of k1: n1 - k1 in slice 0, n1 - 1 - k1 otherwise
+    const int pc = c < H ? c + H : c - H;                           // the same column in the other half
+    const R *par_x = plane + pc + ((L / 2 - 15 * T) - shift - t) * CW;      // [T (15 - m) CW]: slot of k1' - n1/2 = n1/2 - shift - k1
+    const R *par_y = par_x + (L / 2) * CW;
+    const long long out_rows = n / 2 + 1;
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *) (out + (size_t) s * out_rows * 2 * cc_n), 0,
+                                                                          (int) (out_rows * 2 * cc_n * CB), 0x00020000);
+    const bool stores = live && !(self && h == 1);
+    const int ovoff = stores ? ((k2 + n2 * t) * 2 * cc_n + 2 * col) * CB : kOut;
+    const int ostep = T * n2 * 2 * cc_n * CB;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const C a = v[reg_of(m)];
+        C b = C{par_x[T * (15 - m) * CW], par_y[T * (15 - m) * CW]};
+        if (m == 0 && t == 0 && p == 0) b = a;                      // Z[n] := Z[0]
+        const C xa = C{(R) 0.5 * (a.x + b.x), (R) 0.5 * (a.y - b.y)};
+        const C xb = C{(R) 0.5 * (a.y + b.y), (R) -0.5 * (a.x - b.x)};
+        buf_store_pair<kStream>(xa, xb, rout, ovoff, m * ostep);
+    }
+    if (p == 0 && t == 0)                                           // row n/2 = n2 (n1/2): X_a = Re Z, X_b = Im Z
+        buf_store_pair<kStream>(C{zmid.x, (R) 0}, C{zmid.y, (R) 0}, rout, ovoff, 16 * ostep);
+}
+
+template<typename R, int B, bool TWO, int CW>
+__global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO, CW>::WAVES_PER_EU)) void cols_real_merge_kernel(
+    const cpx<R> *__restrict__ in, cpx<R> *__restrict__ work, int cc_n, int n1, int tiles_per_slice, const cpx<R> *__restrict__ tw_full,
+    const cpx<R> *__restrict__ twn) {
+    using C = cpx<R>;
+    using cfg = cols_cfg<R, B, TWO, CW>;
+    constexpr int T = cfg::T, L = cfg::L, NT = cfg::NT, COLS = cfg::COLS, LOGB = ilog2(B);      // L = n2
+    constexpr int CB = (int) sizeof(C);
+    constexpr int kOut = 0x7f000000;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    R *plane = (R *) lds_raw;
+    C *wtab = (C *) (plane + cfg::PLANE);
+    for (int i = threadIdx.x; i < cfg::TABLE; i += NT) wtab[i] = tw_full[(long long) i * cfg::TABLE_STRIDE];
+
+    const int tile = blockIdx.x;
+    const int ct = tile % tiles_per_slice, s = tile / tiles_per_slice;
+    const int tid = threadIdx.x, c = tid % CW, t = tid / CW;
+    const int q = ct * CW + c;                                      // column of the view [n2][n1 cc_n]: (j1, cc)
+    const int inner = n1 * cc_n;
+    const bool live = q < inner;
+    const int j1 = live ? q / cc_n : 0, cc = live ? q - j1 * cc_n : 0;
+    const long long n = (long long) L * n1;
+    const int half = (int) (n / 2);
+    const long long in_rows = n / 2 + 1;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *) (in + (size_t) s * in_rows * 2 * cc_n), 0,
+                                                                         (int) (in_rows * 2 * cc_n * CB), 0x00020000);
+    C v[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {                                  // row k = j1 + n1 (t + T j) of the full spectrum
+        const int k = j1 + n1 * (t + T * j);
+        const bool upper = k > half;
+        const int row = upper ? (int) n - k : k;
+        C ya, yb;
+        buf_load_pair<kStream>(ya, yb, rin, live ? (row * 2 * cc_n + 2 * cc) * CB : kOut, 0);
+        if (row == 0 || row == half) { ya.y = (R) 0; yb.y = (R) 0; }               // dsc_fft.h:227-228: real parts only at bins 0 and n/2
+        // Z = Y_a + i Y_b below the middle, conj Y_a + i conj Y_b above it
+        v[j] = upper ? C{ya.x + yb.y, yb.x - ya.y} : C{ya.x - yb.y, ya.y + yb.x};
+    }
+    __syncthreads();
+    cols_passes<R, B, TWO, CW, true>(v, plane, wtab, tw_full, t, c);       // v[i B + p] = bin k2 = (t + T i) + COLS brev(p) of column q
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *) (work + (size_t) s * n * cc_n), 0, (int) (n * cc_n * CB), 0x00020000);
+    const int voff = live ? (t * inner + q) * CB : kOut;
+    const int step = inner * CB;
+#pragma unroll
+    for (int qq = 0; qq < 32; ++qq) {
+        const int k2 = t + T * (qq / B) + COLS * brev(qq % B, LOGB);
+        const C w = twn[live ? j1 * k2 : 0];
+        buf_store<kStream>(cmulc(v[qq], w), rout, voff, (T * (qq / B) + COLS * brev(qq % B, LOGB)) * step);
+    }
+}
+
+template<typename R, int B, bool TWO, int CW>
+void launch_real_split(const void *work, void *out, long long slices, int cc_n, int n2, const void *tw_full, hipStream_t stream) {
+    using cfg = cols_cfg<R, B, TWO, CW>;
+    constexpr size_t lds = cols_lds_bytes<R, B, TWO, CW>();
+    static unsigned long long attr_devices = 0;
+    if (dsc_first_use_on_device(attr_devices)) {
+        DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) cols_real_split_kernel<R, B, TWO, CW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    }
+    const int tiles = (cc_n + CW / 2 - 1) / (CW / 2);
+    const long long grid = slices * (n2 / 2 + 1) * tiles;
+    DSC_LAUNCH((cols_real_split_kernel<R, B, TWO, CW>), dim3((unsigned) grid), dim3(cfg::NT), lds, stream, (const cpx<R> *) work, (cpx<R> *) out, cc_n,
+               tiles, n2, (const cpx<R> *) tw_full);
+}
+template<typename R, int B, bool TWO, int CW>
+void launch_real_merge(const void *in, void *work, long long slices, int cc_n, int n1, const void *tw_full, const void *twn, hipStream_t stream) {
+    using cfg = cols_cfg<R, B, TWO, CW>;
+    constexpr size_t lds = cols_lds_bytes<R, B, TWO, CW>();
+    static unsigned long long attr_devices = 0;
+    if (dsc_first_use_on_device(attr_devices)) {
+        DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) cols_real_merge_kernel<R, B, TWO, CW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    }
+    const long long inner = (long long) n1 * cc_n;
+    const int tiles = (int) ((inner + CW - 1) / CW);
+    DSC_LAUNCH((cols_real_merge_kernel<R, B, TWO, CW>), dim3((unsigned) (slices * tiles)), dim3(cfg::NT), lds, stream, (const cpx<R> *) in, (cpx<R> *) work,
+               cc_n, n1, tiles, (const cpx<R> *) tw_full, (const cpx<R> *) twn);
+}
+
 #ifndef DSC_COLS_CW_1024
 #define DSC_COLS_CW_1024 16
 #endif
@@ -585,6 +747,49 @@ bool dsc_fft_cols_4step_split(int n, bool single_precision, int *n1, int *n2) {
     *n1 = a;
     *n2 = b;
     return true;
+}
+
+// Real transforms along the middle axis of [slices][n][2 cc_n] reals (see cols_real_split_kernel): cc_n = complex columns = half the real ones.
+// rfft: in = the real tensor, out = [slices][n/2 + 1][2 cc_n] complex.  irfft: the other way round, scale = 1 / n.  work: slices n cc_n complex.
+template<typename R>
+static void launch_real_split_len(int L, const void *work, void *out, long long slices, int cc_n, int n2, const void *tw, hipStream_t st) {
+    constexpr bool SP = sizeof(R) == 4;
+    switch (L) {
+        case 64:   launch_real_split<R, 2, true, 128>(work, out, slices, cc_n, n2, tw, st); break;
+        case 128:  launch_real_split<R, 4, true, 64>(work, out, slices, cc_n, n2, tw, st); break;
+        case 256:  launch_real_split<R, 8, true, 32>(work, out, slices, cc_n, n2, tw, st); break;
+        case 512:  launch_real_split<R, 16, true, SP ? 32 : 16>(work, out, slices, cc_n, n2, tw, st); break;
+        case 1024: launch_real_split<R, 32, true, 16>(work, out, slices, cc_n, n2, tw, st); break;
+        default:   launch_real_split<R, 2, false, SP ? 16 : 8>(work, out, slices, cc_n, n2, tw, st); break;
+    }
+}
+template<typename R>
+static void launch_real_merge_len(int L, const void *in, void *work, long long slices, int cc_n, int n1, const void *tw, const void *twn, hipStream_t st) {
+    constexpr bool SP = sizeof(R) == 4;
+    switch (L) {
+        case 64:   launch_real_merge<R, 2, true, 128>(in, work, slices, cc_n, n1, tw, twn, st); break;
+        case 128:  launch_real_merge<R, 4, true, 64>(in, work, slices, cc_n, n1, tw, twn, st); break;
+        case 256:  launch_real_merge<R, 8, true, 32>(in, work, slices, cc_n, n1, tw, twn, st); break;
+        case 512:  launch_real_merge<R, 16, true, SP ? 32 : 16>(in, work, slices, cc_n, n1, tw, twn, st); break;
+        case 1024: launch_real_merge<R, 32, true, 16>(in, work, slices, cc_n, n1, tw, twn, st); break;
+        default:   launch_real_merge<R, 2, false, SP ? 16 : 8>(in, work, slices, cc_n, n1, tw, twn, st); break;
+    }
+}
+
+void dsc_launch_rfft_cols_4step(const void *in, void *work, void *out, long long slices, int cc_n, int n1, int n2, bool single_precision,
+                                const void *tw1, const void *tw2, const void *twn, hipStream_t stream) {
+    launch_cols_len(in, work, slices, n1 * cc_n, n2, DSC_MODE_C2C, false, single_precision, tw2, nullptr, 1.0, n2, n2, n2,
+                    cols_remap{n1 * cc_n, 1, twn, cc_n}, stream);
+    if (single_precision) launch_real_split_len<float>(n1, work, out, slices, cc_n, n2, tw1, stream);
+    else                  launch_real_split_len<double>(n1, work, out, slices, cc_n, n2, tw1, stream);
+}
+
+void dsc_launch_irfft_cols_4step(const void *in, void *work, void *out, long long slices, int cc_n, int n1, int n2, bool single_precision,
+                                 const void *tw1, const void *tw2, const void *twn, double scale, hipStream_t stream) {
+    if (single_precision) launch_real_merge_len<float>(n2, in, work, slices, cc_n, n1, tw2, twn, stream);
+    else                  launch_real_merge_len<double>(n2, in, work, slices, cc_n, n1, tw2, twn, stream);
+    launch_cols_len(work, out, slices * n2, cc_n, n1, DSC_MODE_C2C, true, single_precision, tw1, nullptr, scale, n1, n1, n1,
+                    cols_remap{n2 * cc_n, n2, nullptr, 1}, stream);
 }
 
 void dsc_launch_fft_cols_4step(const void *in, void *work, void *out, long long slices, int inner, int n1, int n2, dsc_fft_mode mode, bool inverse,

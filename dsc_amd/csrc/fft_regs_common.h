@@ -210,5 +210,32 @@ __device__ __forceinline__ void buf_store(cpx<double> a, __amdgpu_buffer_rsrc_t 
     asm volatile("s_nop 1" : : "v"(data));
 #endif
 }
+// two neighbouring complex values (16 / 32 bytes) in one go
+template<int POL = kCached>
+__device__ __forceinline__ void buf_store_pair(cpx<float> a, cpx<float> b, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const u4 data = __builtin_bit_cast(u4, f4{a.x, a.y, b.x, b.y});
+    __builtin_amdgcn_raw_buffer_store_b128(data, r, voff, soff, POL);
+#ifndef DSC_NO_STORE_HAZARD_PAD
+    asm volatile("s_nop 1" : : "v"(data));                // the 128-bit store-data hazard, see above
+#endif
+}
+template<int POL = kCached>
+__device__ __forceinline__ void buf_store_pair(cpx<double> a, cpx<double> b, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    buf_store<POL>(a, r, voff, soff);
+    buf_store<POL>(b, r, voff, soff + 16);
+}
+template<int POL = kCached>
+__device__ __forceinline__ void buf_load_pair(cpx<float> &a, cpx<float> &b, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 q = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, POL));
+    a = cpx<float>{q.x, q.y};
+    b = cpx<float>{q.z, q.w};
+}
+template<int POL = kCached>
+__device__ __forceinline__ void buf_load_pair(cpx<double> &a, cpx<double> &b, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    a = buf_load<POL>(r, voff, soff, double{});
+    b = buf_load<POL>(r, voff, soff + 16, double{});
+}
 
 }  // namespace
