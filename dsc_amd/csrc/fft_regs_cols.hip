@@ -488,9 +488,10 @@ __global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO,
 //                   plane once (the ownership of section 4.1b across the two halves), every thread separates its sixteen lower bins
 //                   and stores (X_a[k], X_b[k]) — neighbouring columns of row k — in one access.  Slice 0 pairs with itself
 //                   (partner n1 - k1, Z[n] := Z[0]) and so does slice n2 / 2; both halves then hold the same slice and only one stores.
-// inverse   pass 1: cols_real_merge_kernel — Z[k] = Y_a[k] + i Y_b[k] for k <= n/2 and conj(Y_a[n-k]) + i conj(Y_b[n-k]) above: the
-//                   mirror is an ADDRESS (row n - k of the spectrum), no exchange at all; then the inverse pass over j2 and the
-//                   conjugate twiddle, into the work tensor
+// inverse   pass 1: cols_real_merge_kernel — Z[k] = Y_a[k] + i Y_b[k] for k <= n/2 and conj(Y_a[n-k]) + i conj(Y_b[n-k]) above; the rows
+//                   above the middle of column block j1 are the lower rows of block n1 - j1, so a workgroup takes that block PAIR and
+//                   the halves hand each other the conjugate combinations (every spectrum row is read once); then the inverse pass
+//                   over j2 and the conjugate twiddle, into the work tensor
 //           pass 2: the plain complex pass over j1 with the output remap; its output rows are the real rows (x_a, x_b interleaved)
 template<typename R, int B, bool TWO, int CW>
 __global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO, CW>::WAVES_PER_EU)) void cols_real_split_kernel(
@@ -559,53 +560,84 @@ __global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO,
 
 template<typename R, int B, bool TWO, int CW>
 __global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO, CW>::WAVES_PER_EU)) void cols_real_merge_kernel(
-    const cpx<R> *__restrict__ in, cpx<R> *__restrict__ work, int cc_n, int n1, int tiles_per_slice, const cpx<R> *__restrict__ tw_full,
+    const cpx<R> *__restrict__ in, cpx<R> *__restrict__ work, int cc_n, int n1, int tiles_per_pair, const cpx<R> *__restrict__ tw_full,
     const cpx<R> *__restrict__ twn) {
+    // The mirror of the split kernel.  Column block j1 of the view [n2][n1 cc_n] needs the rows k = j1 + n1 j2 of the full spectrum;
+    // those above the middle are the conjugates of rows n - k = (n1 - j1) + n1 (n2 - 1 - j2): the LOWER rows of block n1 - j1.  A
+    // workgroup takes the block pair (j1, n1 - j1), half of its columns each; every thread loads its sixteen lower rows ONCE, keeps
+    // Z = Y_a + i Y_b and hands conj Y_a + i conj Y_b to the other half through the staging plane (one barrier) — each row of the
+    // spectrum is read exactly once.  Block 0 pairs with itself (partner n2 - j2; row n/2 is loaded by its thread), block n1/2 too.
     using C = cpx<R>;
     using cfg = cols_cfg<R, B, TWO, CW>;
-    constexpr int T = cfg::T, L = cfg::L, NT = cfg::NT, COLS = cfg::COLS, LOGB = ilog2(B);      // L = n2
+    constexpr int T = cfg::T, L = cfg::L, NT = cfg::NT, COLS = cfg::COLS, LOGB = ilog2(B), H = CW / 2;      // L = n2
     constexpr int CB = (int) sizeof(C);
     constexpr int kOut = 0x7f000000;
+    static_assert(T >= 2, "lines of 64 points and more");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     R *plane = (R *) lds_raw;
     C *wtab = (C *) (plane + cfg::PLANE);
     for (int i = threadIdx.x; i < cfg::TABLE; i += NT) wtab[i] = tw_full[(long long) i * cfg::TABLE_STRIDE];
 
     const int tile = blockIdx.x;
-    const int ct = tile % tiles_per_slice, s = tile / tiles_per_slice;
-    const int tid = threadIdx.x, c = tid % CW, t = tid / CW;
-    const int q = ct * CW + c;                                      // column of the view [n2][n1 cc_n]: (j1, cc)
-    const int inner = n1 * cc_n;
-    const bool live = q < inner;
-    const int j1 = live ? q / cc_n : 0, cc = live ? q - j1 * cc_n : 0;
+    const int ct = tile % tiles_per_pair, pr = tile / tiles_per_pair;
+    const int n_pairs = n1 / 2 + 1;
+    const int p = pr % n_pairs, s = pr / n_pairs;
+    const int j_a = p, j_b = (n1 - p) % n1;
+    const bool self = j_a == j_b;
+    const int tid = threadIdx.x, c = tid % CW, t = tid / CW, h = c / H;
+    const int col = ct * H + (c - h * H);
+    const bool live = col < cc_n;
+    const int j1 = h ? j_b : j_a;
     const long long n = (long long) L * n1;
     const int half = (int) (n / 2);
     const long long in_rows = n / 2 + 1;
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *) (in + (size_t) s * in_rows * 2 * cc_n), 0,
                                                                          (int) (in_rows * 2 * cc_n * CB), 0x00020000);
     C v[32];
+    R *own_x = plane + c + t * CW, *own_y = own_x + (L / 2) * CW;   // [T j CW]: slot j2 = t + T j of this column
+    {
+        const int voff = live ? ((j1 + n1 * t) * 2 * cc_n + 2 * col) * CB : kOut;   // row k = j1 + n1 (t + T j), columns (2 col, 2 col + 1)
+        const int step = T * n1 * 2 * cc_n * CB;
+        C ya[16], yb[16];
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {                                  // row k = j1 + n1 (t + T j) of the full spectrum
-        const int k = j1 + n1 * (t + T * j);
-        const bool upper = k > half;
-        const int row = upper ? (int) n - k : k;
-        C ya, yb;
-        buf_load_pair<kStream>(ya, yb, rin, live ? (row * 2 * cc_n + 2 * cc) * CB : kOut, 0);
-        if (row == 0 || row == half) { ya.y = (R) 0; yb.y = (R) 0; }               // dsc_fft.h:227-228: real parts only at bins 0 and n/2
-        // Z = Y_a + i Y_b below the middle, conj Y_a + i conj Y_b above it
-        v[j] = upper ? C{ya.x + yb.y, yb.x - ya.y} : C{ya.x - yb.y, ya.y + yb.x};
+        for (int j = 0; j < 16; ++j) buf_load_pair<kStream>(ya[j], yb[j], rin, voff, j * step);
+        C ym_a = C{(R) 0, (R) 0}, ym_b = ym_a;
+        if (p == 0 && t == 0) buf_load_pair<kStream>(ym_a, ym_b, rin, voff, 16 * step);        // row n/2 = n1 (n2/2): block 0, j2 = n2/2
+        if (p == 0 && t == 0) { ya[0].y = (R) 0; yb[0].y = (R) 0; }                            // dsc_fft.h:227-228: real parts only at bins 0, n/2
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            v[j] = C{ya[j].x - yb[j].y, ya[j].y + yb[j].x};                                     // Z[k] = Y_a + i Y_b
+            own_x[T * j * CW] = ya[j].x + yb[j].y;                                              // Z[n - k] = conj Y_a + i conj Y_b
+            own_y[T * j * CW] = yb[j].x - ya[j].y;
+        }
+        v[16] = C{ym_a.x, ym_b.x};                                  // (block 0, thread 0) Z[n/2] = Re Y_a + i Re Y_b; everybody else: overwritten below
     }
-    __syncthreads();
-    cols_passes<R, B, TWO, CW, true>(v, plane, wtab, tw_full, t, c);       // v[i B + p] = bin k2 = (t + T i) + COLS brev(p) of column q
+    __syncthreads();                                                // staging and the twiddle table visible
+    {
+        const int shift = p == 0 ? 0 : 1;                           // partner of j2: n2 - j2 in block 0, n2 - 1 - j2 otherwise
+        const int pc = c < H ? c + H : c - H;
+        const R *par_x = plane + pc + ((L - 31 * T) - shift - t) * CW;      // [T (31 - j) CW]: slot n2 - shift - (t + T j)
+        const R *par_y = par_x + (L / 2) * CW;
+#pragma unroll
+        for (int j = 16; j < 32; ++j) {
+            const C z = C{par_x[T * (31 - j) * CW], par_y[T * (31 - j) * CW]};
+            if (!(j == 16 && t == 0 && p == 0)) v[j] = z;           // (that one is row n/2, loaded above; its slot index n2/2 is not a slot)
+        }
+    }
+    lds_barrier();                                                  // staging reads done before the passes write the plane
+    cols_passes<R, B, TWO, CW, true>(v, plane, wtab, tw_full, t, c);       // v[i B + p] = bin k2 = (t + T i) + COLS brev(p) of column (j1, col)
+    const int inner = n1 * cc_n;
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *) (work + (size_t) s * n * cc_n), 0, (int) (n * cc_n * CB), 0x00020000);
-    const int voff = live ? (t * inner + q) * CB : kOut;
+    const bool stores = live && !(self && h == 1);
+    const int voff = stores ? (t * inner + j1 * cc_n + col) * CB : kOut;
     const int step = inner * CB;
 #pragma unroll
     for (int qq = 0; qq < 32; ++qq) {
         const int k2 = t + T * (qq / B) + COLS * brev(qq % B, LOGB);
-        const C w = twn[live ? j1 * k2 : 0];
+        const C w = twn[j1 * k2];
         buf_store<kStream>(cmulc(v[qq], w), rout, voff, (T * (qq / B) + COLS * brev(qq % B, LOGB)) * step);
     }
+    (void) half;
 }
 
 template<typename R, int B, bool TWO, int CW>
@@ -629,9 +661,9 @@ void launch_real_merge(const void *in, void *work, long long slices, int cc_n, i
     if (dsc_first_use_on_device(attr_devices)) {
         DSC_KERNEL_CHECK(hipFuncSetAttribute((const void *) cols_real_merge_kernel<R, B, TWO, CW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     }
-    const long long inner = (long long) n1 * cc_n;
-    const int tiles = (int) ((inner + CW - 1) / CW);
-    DSC_LAUNCH((cols_real_merge_kernel<R, B, TWO, CW>), dim3((unsigned) (slices * tiles)), dim3(cfg::NT), lds, stream, (const cpx<R> *) in, (cpx<R> *) work,
+    const int tiles = (cc_n + CW / 2 - 1) / (CW / 2);
+    const long long grid = slices * (n1 / 2 + 1) * tiles;
+    DSC_LAUNCH((cols_real_merge_kernel<R, B, TWO, CW>), dim3((unsigned) grid), dim3(cfg::NT), lds, stream, (const cpx<R> *) in, (cpx<R> *) work,
                cc_n, n1, tiles, (const cpx<R> *) tw_full, (const cpx<R> *) twn);
 }
 
@@ -742,8 +774,10 @@ bool dsc_fft_cols_4step_split(int n, bool single_precision, int *n1, int *n2) {
     int lg = 0;
     while ((1 << lg) < n) ++lg;
     if ((1 << lg) != n || lg < 10) return false;
-    const int a = 1 << (lg / 2), b = n / a;                 // a <= b; the longer lines go to pass 1, whose tiles are always whole
-    if (a < 32 || b > (single_precision ? 2048 : 2048)) return false;
+    int a = 1 << (lg / 2), b = n / a;                       // a <= b; the longer lines go to pass 1, whose tiles are always whole
+    static const int skew = [] { const char *e = getenv("DSC_COLS_4STEP_SKEW"); return e ? atoi(e) : 0; }();      // experiments: n1 >> skew
+    for (int i = 0; i < skew && a > 64 && b < 2048; ++i) { a >>= 1; b <<= 1; }
+    if (a < 32 || b > 2048) return false;
     *n1 = a;
     *n2 = b;
     return true;

@@ -484,6 +484,49 @@ def test_long_complex_transforms_along_a_non_last_axis(dsc, dt):
     assert rel_l2(got, np.fft.fft(z.astype(np.complex128), n=4096, axis=0)) <= tol
 
 
+@pytest.mark.parametrize('dt', [np.float32, np.float64])
+def test_long_real_transforms_along_a_non_last_axis(dsc, dt):
+    """dsc_rfft / dsc_irfft along a non-last axis at 8192 points and more, an even number of columns: two neighbouring real columns travel
+    as one complex column through the four-step of the column kernel; the two spectra are separated in its second pass (slice pairs
+    (k2, n2 - k2)) and merged in the first pass of the inverse (block pairs (j1, n1 - j1)).  Every element against numpy in f64, one
+    column per case against the oracle; exact zeros in the imaginary parts of bins 0 and n/2; irfft ignores those of its input
+    (dsc_fft.h:227-228); an odd number of columns and padded calls leave the route."""
+    from oracle import port
+    rng = np.random.default_rng(8)
+    tol = 1e-6 if dt == np.float32 else 1e-14
+    cdt = np.complex64 if dt == np.float32 else np.complex128
+    for shape, axis in (((8192, 40), 0), ((16384, 34), 0), ((3, 32768, 18), 1), ((65536, 24), 0), ((2, 131072, 16), 1)):
+        x = rng.standard_normal(shape).astype(dt)
+        got = dsc.rfft(dsc.from_numpy(x), axis=axis).numpy()
+        assert dsc.last_fft_path() == 'cols_4step_real', (shape, dsc.last_fft_path())
+        want = np.fft.rfft(x.astype(np.float64), axis=axis)
+        assert rel_l2(got, want) <= tol, shape
+        assert float(np.max(np.abs(got - want)) / np.max(np.abs(want))) <= 8 * tol, shape
+        assert not np.take(got, 0, axis=axis).imag.any() and not np.take(got, -1, axis=axis).imag.any()
+        col = (slice(None), shape[1] - 1) if axis == 0 else (shape[0] - 1, slice(None), 3)
+        assert_close(got[col], port.rfft(np.ascontiguousarray(x[col])), what=f'rfft {shape} one column against the oracle')
+        Y = want.astype(cdt)
+        Yq = Y.copy()
+        edge0 = [slice(None)] * Y.ndim
+        edge0[axis] = 0
+        edge1 = list(edge0)
+        edge1[axis] = -1
+        Yq[tuple(edge0)] += 2j
+        Yq[tuple(edge1)] -= 3j
+        back = dsc.irfft(dsc.from_numpy(Yq), axis=axis).numpy()
+        assert dsc.last_fft_path() == 'cols_4step_real', (shape, dsc.last_fft_path())
+        assert rel_l2(back, np.fft.irfft(Y.astype(np.complex128), axis=axis)) <= tol, shape
+        assert_close(back[col], port.irfft(np.ascontiguousarray(Yq[col])), what=f'irfft {shape} one column against the oracle')
+    x = rng.standard_normal((8192, 33)).astype(dt)                           # odd number of columns: no column pairs
+    got = dsc.rfft(dsc.from_numpy(x), axis=0).numpy()
+    assert dsc.last_fft_path() != 'cols_4step_real'
+    assert rel_l2(got, np.fft.rfft(x.astype(np.float64), axis=0)) <= tol
+    x = rng.standard_normal((8000, 32)).astype(dt)                           # zero padded to 8192
+    got = dsc.rfft(dsc.from_numpy(x), n=8192, axis=0).numpy()
+    assert dsc.last_fft_path() != 'cols_4step_real'
+    assert rel_l2(got, np.fft.rfft(x.astype(np.float64), n=8192, axis=0)) <= tol
+
+
 def test_f64_lines_of_16384_points_more_lines_than_workgroups(dsc):
     """f64 lines of 16384 complex points run in a PERSISTENT form of fft_mid_kernel: one group per CU walks lines blockIdx.x,
     + gridDim.x, ... and requests its next line while it stores the current one.  600 lines on 256 CUs: every group walks two or
