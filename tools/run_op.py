@@ -85,6 +85,10 @@ CASES['rfft_f64_131072'] = _rfft_case(131072, 2048, f64=True)
 CASES['rfft_f64_65536'] = _rfft_case(65536, 4096, f64=True)
 CASES['irfft_f64_65536'] = _rfft_case(65536, 4096, f64=True, inverse=True)
 CASES['fft_c64_32768'] = _fft_case(32768, 4096, f64=True)
+CASES['rfft_f64_32768'] = _rfft_case(32768, 8192, f64=True)      # the persistent f64 lines of 16384 points (round 3)
+CASES['irfft_f64_32768'] = _rfft_case(32768, 8192, f64=True, inverse=True)
+CASES['fft_c64_16384'] = _fft_case(16384, 8192, f64=True)
+CASES['irfft_f32_32768'] = _rfft_case(32768, 16384, inverse=True)
 CASES['irfft_f64_131072'] = _rfft_case(131072, 2048, f64=True, inverse=True)
 
 
@@ -161,7 +165,8 @@ def _axis0_case(n, cols, kind):
     return make
 
 
-for _n, _cols in ((256, 1 << 20), (1024, 1 << 18), (2048, 1 << 17)):
+# 8192 and 65536 points along axis 0: the four-step routes of the column kernel (round 3)
+for _n, _cols in ((256, 1 << 20), (1024, 1 << 18), (2048, 1 << 17), (8192, 1 << 15), (65536, 1 << 12)):
     for _kind in ('rfft', 'irfft', 'fft'):
         CASES[f'{_kind}_axis0_{_n}x{_cols if _kind != "fft" else _cols // 2}'] = _axis0_case(_n, _cols, _kind)
 
