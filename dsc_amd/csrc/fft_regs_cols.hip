@@ -667,6 +667,18 @@ void launch_real_merge(const void *in, void *work, long long slices, int cc_n, i
                cc_n, n1, tiles, (const cpx<R> *) tw_full, (const cpx<R> *) twn);
 }
 
+#ifndef DSC_COLS_CW_64          // columns per tile of the f32 forms (A/B knobs, tools/build_file_variant.sh)
+#define DSC_COLS_CW_64 128
+#endif
+#ifndef DSC_COLS_CW_128
+#define DSC_COLS_CW_128 64
+#endif
+#ifndef DSC_COLS_CW_256
+#define DSC_COLS_CW_256 32
+#endif
+#ifndef DSC_COLS_CW_512
+#define DSC_COLS_CW_512 32
+#endif
 #ifndef DSC_COLS_CW_1024
 #define DSC_COLS_CW_1024 16
 #endif
@@ -731,10 +743,10 @@ static void launch_cols_len(const void *in, void *out, long long slices, int inn
     if (single_precision) {
         switch (L) {
             case 32:   launch_cols_mode<float, 1, true, 256>(COLS_ARGS); break;
-            case 64:   launch_cols_mode<float, 2, true, 128>(COLS_ARGS); break;
-            case 128:  launch_cols_mode<float, 4, true, 64>(COLS_ARGS); break;
-            case 256:  launch_cols_mode<float, 8, true, 32>(COLS_ARGS); break;
-            case 512:  launch_cols_mode<float, 16, true, 32>(COLS_ARGS); break;
+            case 64:   launch_cols_mode<float, 2, true, DSC_COLS_CW_64>(COLS_ARGS); break;
+            case 128:  launch_cols_mode<float, 4, true, DSC_COLS_CW_128>(COLS_ARGS); break;
+            case 256:  launch_cols_mode<float, 8, true, DSC_COLS_CW_256>(COLS_ARGS); break;
+            case 512:  launch_cols_mode<float, 16, true, DSC_COLS_CW_512>(COLS_ARGS); break;
             case 1024:                                  // real rows are 4 B per column: 32 columns make them whole 128-B lines
                 if (mode == DSC_MODE_R2C_PACKED) launch_cols_mode<float, 32, true, 32>(COLS_ARGS);
                 else                             launch_cols_mode<float, 32, true, DSC_COLS_CW_1024>(COLS_ARGS);
