@@ -24,7 +24,7 @@ for case in range(n_cases):
         trailing.append(d)
         left = max(1, left // d)
     trailing.append(left)
-    lead = [int(rng.integers(1, 4))] if rng.integers(0, 2) and n * int(np.prod(trailing)) * 3 <= budget * 2 else []
+    lead = [int(rng.integers(1, 4))] if rng.integers(0, 2) and nd < 4 and n * int(np.prod(trailing)) * 3 <= budget * 2 else []       # at most 4 dimensions
     shape = tuple(lead + [n] + trailing)
     axis = len(lead)
     f64 = bool(rng.integers(0, 2))
