@@ -248,7 +248,8 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
     lines_of(j.out, j.slot, &n_lines, &inner, &lout);
 
     // Long complex transforms along a non-last axis (dsc_fft / dsc_ifft, complex or real input, full lines): four-step in two passes of
-    // the column kernel — two streaming passes with whole tile rows instead of the three of the transpose route below
+    // the column kernel — two streaming passes with whole tile rows instead of the three of the transpose route below; 4096-point lines
+    // only from 64 columns (below that the one-pass kernel's 8-column tiles hold whole rows: 34 - 44 % against 10 - 27 %)
     // (33 - 34 % of the roofline against 20 - 22 %; 4096-point c32 lines: against 24 % for the one-pass column kernel with its 64-B pieces).  One full-size
     // temporary in the main arena.  (DSC_COLS_4STEP_MIN: smallest length that takes this route; 0 switches it off.)
     {
@@ -256,7 +257,7 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
         const int x_n = j.x->shape[j.slot], out_n = j.out->shape[j.slot];
         int n1 = 0, n2 = 0;
         if (inner >= 8 && min_4step > 0 && j.L >= min_4step && (j.mode == DSC_MODE_C2C || j.mode == DSC_MODE_R2C_CAST) && x_n == j.L && j.in_len == j.L &&
-            out_n == j.L && j.L <= (1 << 22) && dsc_fft_cols_4step_split(j.L, sp, &n1, &n2)) {
+            out_n == j.L && j.L <= (1 << 22) && (j.L > 4096 || inner >= 64) && dsc_fft_cols_4step_split(j.L, sp, (int) inner, &n1, &n2)) {
             const size_t csz = dsc_dtype_size(j.out->dtype);
             const size_t slice_bytes = (size_t) j.L * inner * csz;                     // pass 1 addresses a whole [n][inner] slice with 32-bit offsets
             const size_t work_bytes = (size_t) j.out->ne * csz;
@@ -286,7 +287,7 @@ static void run_job(dsc_ctx *ctx, const fft_job &j) {
                                                         : (x_n == j.L + 1 && j.in_len == j.L + 1 && out_n == n);
         int n1 = 0, n2 = 0;
         if (packed && full && inner >= 16 && inner % 2 == 0 && min_real > 0 && n >= min_real && n <= (1 << 22) &&
-            dsc_fft_cols_4step_split((int) n, sp, &n1, &n2) && n1 >= 64) {
+            dsc_fft_cols_4step_split((int) n, sp, 1 << 20, &n1, &n2) && n1 >= 64 && n2 >= 64) {   // balanced: narrower pass-2 tiles would widen the merge kernel's (measured)
             const dsc_dtype cdt = sp ? DSC_C32 : DSC_C64;
             const size_t csz = dsc_dtype_size(cdt);
             const long long slices = n_lines / inner, cc_n = inner / 2;

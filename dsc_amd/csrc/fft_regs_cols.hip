@@ -782,14 +782,29 @@ void dsc_launch_fft_regs_cols(const void *in, void *out, long long slices, int i
 // Both passes move pieces of a whole tile row (32 - 128 columns); the route through two transposes and a row transform is three
 // passes.  mode: DSC_MODE_C2C or DSC_MODE_R2C_CAST (real input, widened while pass 1 loads).  work: slices n inner complex.
 // tw1 / tw2: W_{n1}^m / W_{n2}^m (the complex plans of the two lengths), twn: W_n^m, m < n.  The caller checks the 2 GiB slice limit.
-bool dsc_fft_cols_4step_split(int n, bool single_precision, int *n1, int *n2) {
+// columns per tile of the column kernel at complex length L (the table of launch_cols_len)
+static int cols_tile_width(int L, bool single_precision) {
+    if (L <= 32) return 256;
+    if (L == 64) return DSC_COLS_CW_64;
+    if (L == 128) return DSC_COLS_CW_128;
+    if (L == 256) return DSC_COLS_CW_256;
+    if (single_precision) return L == 512 ? DSC_COLS_CW_512 : L <= 2048 ? 16 : 8;
+    return L <= 1024 ? 16 : 8;
+}
+
+// n = n1 n2: balanced (n1 <= n2: the longer lines go to pass 1, whose tiles are always whole); when the tensor has fewer columns than a
+// pass-2 tile of n1-point lines is wide, bits move from n2 to n1 — longer lines have narrower tiles — as long as n2 stays >= 64
+// (measured, tools/bench_axis_small_inner.py: 65536 points x 8 columns 22.6 % with 256 x 256).  cols: complex columns pass 2 sees.
+bool dsc_fft_cols_4step_split(int n, bool single_precision, int cols, int *n1, int *n2) {
     int lg = 0;
     while ((1 << lg) < n) ++lg;
     if ((1 << lg) != n || lg < 10) return false;
-    int a = 1 << (lg / 2), b = n / a;                       // a <= b; the longer lines go to pass 1, whose tiles are always whole
+    int a = 1 << (lg / 2), b = n / a;
     static const int skew = [] { const char *e = getenv("DSC_COLS_4STEP_SKEW"); return e ? atoi(e) : 0; }();      // experiments: n1 >> skew
     for (int i = 0; i < skew && a > 64 && b < 2048; ++i) { a >>= 1; b <<= 1; }
-    if (a < 32 || b > 2048) return false;
+    static const bool widen = getenv("DSC_COLS_4STEP_NO_WIDEN") == nullptr;
+    while (widen && cols_tile_width(a, single_precision) > cols && b >= 128 && a < 2048) { a <<= 1; b >>= 1; }
+    if (a < 32 || b < 32 || a > 2048 || b > 2048) return false;
     *n1 = a;
     *n2 = b;
     return true;

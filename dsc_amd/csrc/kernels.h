@@ -112,7 +112,7 @@ bool   dsc_fft_regs_cols_supports(int L, dsc_fft_mode mode, bool single_precisio
 void   dsc_launch_fft_regs_cols(const void *in, void *out, long long slices, int inner, int L, dsc_fft_mode mode, bool inverse, bool single_precision,
                                 const void *tw_full, const void *tw_real, double scale, int in_axis, int in_len, int out_axis, hipStream_t stream);
 // complex transform of n = n1 n2 points along the middle axis of [slices][n][inner] in two passes of the column kernel (four-step)
-bool   dsc_fft_cols_4step_split(int n, bool single_precision, int *n1, int *n2);
+bool   dsc_fft_cols_4step_split(int n, bool single_precision, int cols, int *n1, int *n2);
 // real transforms of n = n1 n2 points along the middle axis of [slices][n][2 cc_n] reals: two neighbouring columns as one complex column
 void   dsc_launch_rfft_cols_4step(const void *in, void *work, void *out, long long slices, int cc_n, int n1, int n2, bool single_precision,
                                   const void *tw1, const void *tw2, const void *twn, hipStream_t stream);
