@@ -464,7 +464,7 @@ def test_long_complex_transforms_along_a_non_last_axis(dsc, dt):
     from oracle import port
     rng = np.random.default_rng(4)
     tol = 1e-6 if dt == np.complex64 else 1e-14
-    for shape, axis in (((4096, 40), 0), ((8192, 33), 0), ((3, 16384, 17), 1), ((65536, 24), 0), ((2, 131072, 9), 1)):
+    for shape, axis in (((4096, 72), 0), ((8192, 33), 0), ((3, 16384, 17), 1), ((65536, 24), 0), ((2, 131072, 9), 1)):
         z = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(dt)
         for name in ('fft', 'ifft'):
             got = getattr(dsc, name)(dsc.from_numpy(z), axis=axis).numpy()
@@ -482,6 +482,14 @@ def test_long_complex_transforms_along_a_non_last_axis(dsc, dt):
     got = dsc.fft(dsc.from_numpy(z), n=4096, axis=0).numpy()                 # cropped: not a full line
     assert dsc.last_fft_path() != 'cols_4step'
     assert rel_l2(got, np.fft.fft(z.astype(np.complex128), n=4096, axis=0)) <= tol
+    z = z[:4096, :]                                                          # 4096 points with fewer than 64 columns: the one-pass kernel's
+    got = dsc.fft(dsc.from_numpy(np.ascontiguousarray(z)), axis=0).numpy()   # 8-column tiles hold whole rows and win (f64: the transposes)
+    assert dsc.last_fft_path() != 'cols_4step'
+    assert rel_l2(got, np.fft.fft(z.astype(np.complex128), axis=0)) <= tol
+    z = (rng.standard_normal((65536, 8)) + 1j * rng.standard_normal((65536, 8))).astype(dt)    # few columns, long lines: n1 grows (1024 x 64)
+    got = dsc.fft(dsc.from_numpy(z), axis=0).numpy()
+    assert dsc.last_fft_path() == 'cols_4step'
+    assert rel_l2(got, np.fft.fft(z.astype(np.complex128), axis=0)) <= tol
 
 
 @pytest.mark.parametrize('dt', [np.float32, np.float64])
@@ -805,9 +813,9 @@ def test_column_kernel_every_length_and_mode(dsc, dt, L):
     # complex transform of length L along axis 1 of [2, L, inner]
     z = (rng.standard_normal((2, L, inner)) + 1j * rng.standard_normal((2, L, inner))).astype(cdt)
     Z = dsc.fft(dsc.from_numpy(z), axis=1)
-    # full lines of 4096 points take the four-step route (two passes of this kernel at 64 points); the one-pass 4096-point form
-    # keeps the padded / cropped calls (below)
-    assert dsc.last_fft_path() == ('cols_4step' if L == 4096 else 'regs_cols'), dsc.last_fft_path()
+    # (full lines of 4096 points with 64 columns or more take the four-step route, two passes of this kernel at 64 points:
+    # test_long_complex_transforms_along_a_non_last_axis; with the 21 columns here the one-pass form stays)
+    assert (dsc.last_fft_path() == 'regs_cols') == on_cols, dsc.last_fft_path()
     assert_close(Z.numpy(), port.fft(z, -1, 1), what=f'fft L={L}')
     assert_close(dsc.ifft(dsc.from_numpy(z), axis=1).numpy(), port.ifft(z, -1, 1), what=f'ifft L={L}')
     zs = z[:, :L - 11]                                     # zero padded: axis shorter than the transform
