@@ -166,7 +166,19 @@ __global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO,
     constexpr bool PIPE = cfg::PIPE && !TWO;
     // the inverse pre-pass with every pair handled once (see above): the f32 forms lose their spills with it (14 - 25 -> 0 - 4),
     // the f64 forms get more (6 - 35 -> 19 - 54: hipcc starts all sixteen pairs at once), so they keep the two-exchange form
+#ifdef DSC_COLS_NO_PAIR_ONCE
+    constexpr bool PAIR_ONCE = false;
+#else
     constexpr bool PAIR_ONCE = sizeof(R) == 4;
+#endif
+    // The real passes that move only the upper halves through the staging plane (fft_regs_mid.hip, "who owns which bin": thread t of a
+    // column holds the bins t + T m, its partners L - k are upper bins of thread T - t of the same column): forward post-pass and, where
+    // PAIR_ONCE is off, the inverse pre-pass.
+#ifdef DSC_COLS_OLD_REAL_PASSES
+    constexpr bool POST_ONCE = false, PRE_ONCE = false;
+#else
+    constexpr bool POST_ONCE = T >= 2 && !PIPE, PRE_ONCE = T >= 2;
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     R *plane = (R *) lds_raw;
     C *wtab = (C *) (plane + cfg::PLANE);
@@ -270,7 +282,41 @@ __global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO,
             }
             v[16].y = -v[16].y;                                     // Z[L/2] = conj Y[L/2]
         }
-        if constexpr (MODE == DSC_MODE_C2R_PACKED && !PAIR_ONCE && T != 1) {
+        if constexpr (MODE == DSC_MODE_C2R_PACKED && !PAIR_ONCE && T != 1 && PRE_ONCE) {
+            // pair (k, L - k), k = t + T j, j < 16: a = Y[k] (own), b = Y[L-k] = an upper bin of thread T - t; the upper halves go to the
+            // staging plane (slot of bin b: b - L/2; x plane rows [0, L/2), y plane [L/2, L)), one barrier, every pair is computed once,
+            // Z[L-k] goes back into the slot b came from (this thread is its only reader), second barrier, everybody collects its upper half
+            const int tid = tid_now(), c = tid % CW, t = tid / CW;
+            R *stage = plane + c;
+            const C wbase = tw_real[t];
+            C yl = request_mid(tile);                               // bin L (thread 0)
+            if (t == 0) { v[0].y = (R) 0; yl.y = (R) 0; }           // bins 0 and L: real parts only (dsc_fft.h:227-228)
+            R *own_x = stage + t * CW, *own_y = own_x + (L / 2) * CW;
+            R *par_x = stage + ((L / 2 - 15 * T) - t) * CW, *par_y = par_x + (L / 2) * CW;
+#pragma unroll
+            for (int j = 16; j < 32; ++j) { own_x[T * (j - 16) * CW] = v[j].x; own_y[T * (j - 16) * CW] = v[j].y; }
+            if (t == 0) own_y[0] = -v[16].y;                        // bin L/2 pairs with itself: Z[L/2] = conj Y[L/2]
+            lds_barrier();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const C a = v[j];
+                C b = C{par_x[T * (15 - j) * CW], par_y[T * (15 - j) * CW]};
+                if (j == 0 && t == 0) b = yl;
+                const C w = cmul(wbase, C{(R) root64_re(j), (R) root64_im(j)});        // W_2L^{t + T j} = W_2L^t W_64^j
+                const R wqx = (R) 0.5 * w.y, wqy = (R) 0.5 * w.x;
+                const R sx = (R) 0.5 * (a.x + b.x), sy = (R) 0.5 * (a.y - b.y), dx = a.x - b.x, dy = a.y + b.y;
+                const R wdx = dx * wqx - dy * wqy, wdy = dx * wqy + dy * wqx;
+                v[j] = C{sx + wdx, sy + wdy};
+                if (!(j == 0 && t == 0)) {                          // Z[L] is no bin
+                    par_x[T * (15 - j) * CW] = sx - wdx;
+                    par_y[T * (15 - j) * CW] = wdy - sy;
+                }
+            }
+            lds_barrier();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[16 + j] = C{own_x[T * j * CW], own_y[T * j * CW]};
+        }
+        if constexpr (MODE == DSC_MODE_C2R_PACKED && !PAIR_ONCE && T != 1 && !PRE_ONCE) {
             // Z[k] = (a + conj b)/2 + wq (a - conj b), a = Y[k], b = Y[L-k], wq = (i/2) conj(W_2L^k), k = T j1 + t (dsc_fft.h:194-228):
             // every thread for its own 32 bins, b through the staging plane one component at a time
             const int tid = tid_now(), c = tid % CW, t = tid / CW;
@@ -422,6 +468,35 @@ __global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO,
 #pragma unroll
                 for (int q = 0; q < 32; ++q) put(q);
             }
+        } else if constexpr (POST_ONCE) {
+            // packed-real post-pass (dsc_fft.h:199-225): only the upper halves travel (see above), one barrier
+            const C wbase = tw_real[t];
+            auto reg_of = [](int m) constexpr { return (m % CPT) * B + brev(m / CPT, LOGB); };      // register that holds bin t + T m
+            R *own_x = stage + t * CW, *own_y = own_x + (L / 2) * CW;
+            const R *par_x = stage + ((L / 2 - 15 * T) - t) * CW, *par_y = par_x + (L / 2) * CW;
+#pragma unroll
+            for (int m = 16; m < 32; ++m) { own_x[T * (m - 16) * CW] = v[reg_of(m)].x; own_y[T * (m - 16) * CW] = v[reg_of(m)].y; }
+            const C zmid = v[reg_of(16)];                           // thread 0: bin L/2, which pairs with itself
+            lds_barrier();
+            const int step = inner * CB;
+            const int voff_k = live ? (t * inner + col) * CB : kOut;
+            const int voff_m = live ? (((L - 15 * T) - t) * inner + col) * CB : kOut;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const C a = v[reg_of(m)];
+                C b = C{par_x[T * (15 - m) * CW], par_y[T * (15 - m) * CW]};
+                if (m == 0 && t == 0) b = a;                        // Z[L] := Z[0]
+                const C w = cmul(wbase, C{(R) root64_re(m), (R) root64_im(m)});        // W_2L^{t + T m} = W_2L^t W_64^m
+                const R wqx = (R) 0.5 * w.y, wqy = (R) -0.5 * w.x;
+                const R sx = a.x + b.x, sy = a.y - b.y, dx = a.x - b.x, dy = a.y + b.y;
+                const R wdx = dx * wqx - dy * wqy, wdy = dx * wqy + dy * wqx;
+                C xk = C{(R) 0.5 * sx + wdx, (R) 0.5 * sy + wdy};
+                C xm = C{(R) 0.5 * sx - wdx, wdy - (R) 0.5 * sy};
+                if (m == 0 && t == 0) { xk.y = (R) 0; xm.y = (R) 0; }           // dsc_fft.h:221-225 stores exact zeros
+                buf_store<kStream>(C{xk.x * scale, xk.y * scale}, rout, voff_k, T * m * step);
+                buf_store<kStream>(C{xm.x * scale, xm.y * scale}, rout, voff_m, T * (15 - m) * step);
+            }
+            if (t == 0) buf_store<kStream>(C{zmid.x * scale, -zmid.y * scale}, rout, voff_k, (L / 2) * step);     // k = L/2: a = b, W_2L^{L/2} = -i
         } else {
             // packed-real post-pass (dsc_fft.h:199-225), one thread per PAIR (k, L-k), k = t + T i < L/2, plus k = L/2 (thread 0)
             const C wbase = tw_real[t];
