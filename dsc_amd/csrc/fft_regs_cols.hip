@@ -166,10 +166,13 @@ __global__ __launch_bounds__((cols_cfg<R, B, TWO, CW>::NT), (cols_cfg<R, B, TWO,
     constexpr bool PIPE = cfg::PIPE && !TWO;
     // the inverse pre-pass with every pair handled once (see above): the f32 forms lose their spills with it (14 - 25 -> 0 - 4),
     // the f64 forms get more (6 - 35 -> 19 - 54: hipcc starts all sixteen pairs at once), so they keep the two-exchange form
-#ifdef DSC_COLS_NO_PAIR_ONCE
-    constexpr bool PAIR_ONCE = false;
-#else
+    // (later in round 3: the one-exchange pre-pass below needs no second set of loads and measured equal or better — irfft along axis 0,
+    // 1024 points 63.1 -> 65.3 %, 512: 67.0 -> 67.8 %, the others within 0.3 points (tools/r03_call_aa.sh) — so the form that loads the
+    // partners from memory is off; -DDSC_COLS_PAIR_ONCE brings it back for f32)
+#ifdef DSC_COLS_PAIR_ONCE
     constexpr bool PAIR_ONCE = sizeof(R) == 4;
+#else
+    constexpr bool PAIR_ONCE = false;
 #endif
     // The real passes that move only the upper halves through the staging plane (fft_regs_mid.hip, "who owns which bin": thread t of a
     // column holds the bins t + T m, its partners L - k are upper bins of thread T - t of the same column): forward post-pass and, where
