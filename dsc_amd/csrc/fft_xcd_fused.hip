@@ -475,7 +475,11 @@ __global__ __launch_bounds__(kNT, (kNT == 512 ? 4 : DSC_FUSED_WG_PER_CU)) void f
             }
             if (next < rows) request(cur, cur_last, next);          // v is dead: its registers take the next row
             dft16<R, false>(u);                                     // over t' -> k: u[p] = Z[k1 = t + 16 brev(p)][col]
+#ifdef DSC_FUSED_SKIP_REAL_PASS          // timing experiment only (wrong results): what does the packed-real pass cost?
+            if constexpr (true) {
+#else
             if constexpr (!REAL) {
+#endif
 #pragma unroll
                 for (int p = 0; p < 16; ++p) st<kStream>(u[p], rb, boff, 16 * brev(p, 4) * BSTEP);
             } else {
