@@ -156,6 +156,24 @@ def test_out_argument_and_views(dsc):
     assert out._c_ptr.contents.backend == 1
 
 
+@pytest.mark.parametrize('dt', [np.complex64, np.complex128])
+def test_complex_transforms_in_place(dsc, dt):
+    """dsc_fft / dsc_ifft with out == x: the reference gathers a line into scratch before it scatters (dsc.cpp:1990-2040), so in place
+    is legal there; every route a complex transform can take here (register rows of several sizes, the team kernel, the two-kernel
+    route, the column kernel in one pass and as a four-step) must read a line, a tile or the whole tensor before it overwrites it."""
+    rng = np.random.default_rng(12)
+    tol = 2e-6 if dt == np.complex64 else 1e-13
+    for shape, axis in (((300, 64), -1), ((70, 1024), -1), ((6, 32768), -1), ((5, 65536), -1), ((3, 262144), -1), ((2, 1048576), -1),
+                        ((256, 300), 0), ((2048, 40), 0), ((4096, 72), 0), ((65536, 24), 0), ((3, 8192, 20), 1), ((16, 40), 0)):
+        z = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(dt)
+        for name in ('fft', 'ifft'):
+            t = dsc.from_numpy(z)
+            r = getattr(dsc, name)(t, out=t, axis=axis)
+            want = getattr(np.fft, name)(z.astype(np.complex128), axis=axis)
+            assert rel_l2(t.numpy(), want) <= tol, (name, shape, axis, dsc.last_fft_path())
+            assert r._c_ptr.contents.data == t._c_ptr.contents.data
+
+
 def test_arena_reuse_and_double_free(dsc):
     import dsc_amd._bindings as B
     from dsc_amd.context import _get_ctx
